@@ -1,0 +1,183 @@
+/*
+ * sdv_hip.h - C ABI of libsdv_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * StableDiffusionWalkPipeline hot path.
+ *
+ * The reference (nateraw/stable-diffusion-videos) has no FFI layer: its hot path is five Python
+ * calls into diffusers/ATen (SURVEY.md section 8b "inner boundary"):
+ *     self.unet(x, t, encoder_hidden_states=ctx).sample      stable_diffusion_pipeline.py:418
+ *     noise_pred_uncond + g * (text - uncond)                stable_diffusion_pipeline.py:422-423
+ *     self.scheduler.step(eps, t, latents).prev_sample       stable_diffusion_pipeline.py:426
+ *     self.vae.decode(latents).sample                        stable_diffusion_pipeline.py:433
+ *     torch.lerp(...) / slerp(...)                           stable_diffusion_pipeline.py:467-468, utils.py:42-66
+ * Each entry point below replaces the ATen/cuDNN/cuBLAS work one of those lines dispatches; the
+ * line it replaces is cited on the declaration.  INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer (HBM) unless named host_*.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no sync, no
+ *     allocation) so the whole denoise step is hipGraph-capturable.
+ *   - bf16 = raw uint16 storage; activations are NHWC ([N*H*W, C] row-major == token-major).
+ *   - return value: 0 = ok, negative = argument error (message via sdv_last_error()).
+ */
+#ifndef SDV_HIP_H
+#define SDV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t sdv_bf16;
+
+#define SDV_OK 0
+#define SDV_ERR_ARG (-1)
+#define SDV_ERR_LAUNCH (-2)
+
+const char* sdv_last_error(void);
+int sdv_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM on the bf16 MFMA pipes (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
+ *     C[b][m][n] = epi( alpha * sum_k X[b][m][k] * W[b][n][k] )
+ * `X` rows are activations (or any K-contiguous operand), `W` rows are weights.  K % 64 == 0.
+ * Replaces: every nn.Linear / Conv2d(1x1) / Conv2d(3x3) / torch.matmul inside
+ * UNet2DConditionModel.forward (stable_diffusion_pipeline.py:418) and AutoencoderKL.decode (:433).
+ *
+ * mode      0 dense rows; 1 conv3x3 stride 1 pad 1; 2 conv3x3 stride 2 pad 1;
+ *           3 nearest-2x upsample followed by conv3x3 pad 1 (Upsample2D), gathered on the fly.
+ *           For conv modes M = nimg*Hout*Wout, K = Cin and W is [N][3][3][Cin] (OHWI), ldw = 9*Cin.
+ * X2/C1     optional second source: channels [0,C1) come from X, [C1,K) from X2 (skip-connection
+ *           concat without materialising it).  C1 % 64 == 0.
+ * epi       0: bf16 out = acc*alpha (+bias) (+R)      [ldc, residual R with ldr]
+ *           1: GEGLU: W rows pre-interleaved in 32-row blocks [value | gate]; out is [M][N/2]
+ *           2: as 0, then SiLU
+ * bias      fp32; bias_mode 1 = per n, 2 = per m.  If step_ptr != NULL the bias row used is
+ *           bias + (*step_ptr) * bias_step_stride (per-denoise-step time-embedding bias table).
+ * zero_page >= 256 bytes of zeros in HBM (source of the conv padding halo).
+ * batch     blockIdx.z; element strides sX/sW/sC/sR (0 = shared).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdv_gemm_args {
+    const sdv_bf16* X;
+    const sdv_bf16* X2;
+    const sdv_bf16* W;
+    const float* bias;
+    const sdv_bf16* R;
+    sdv_bf16* C;
+    const int32_t* step_ptr;
+    const sdv_bf16* zero_page;
+    int64_t sX, sW, sC, sR;
+    int32_t M, N, K;
+    int32_t ldx, ldx2, C1, ldw, ldc, ldr;
+    int32_t mode, Hin, Win, Hout, Wout, circular;
+    int32_t epi, bias_mode, bias_step_stride;
+    int32_t batch;
+    int32_t tile;    /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 */
+    float alpha;
+} sdv_gemm_args;
+
+int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flash-style attention, softmax(Q K^T * scale) V, never materialising the score matrix.
+ * Replaces CrossAttention.forward inside the UNet (self: Lk = Lq; cross: Lk = 77).
+ *   Q  [B][Lq][ldq]   head h at columns [h*dh, (h+1)*dh)
+ *   K  [B][Lk][ldk]   same head layout
+ *   Vt [B][H*dh][ldv] V TRANSPOSED (row = channel, column = key), ldv >= roundup(Lk,64), the
+ *                     columns >= Lk must be finite (zero-filled)
+ *   O  [B][Lq][ldo]
+ * dh in {40, 64, 80, 160}.
+ * ------------------------------------------------------------------------------------------ */
+int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O,
+                       int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dh,
+                       int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
+
+/* row softmax in place over bf16 rows (VAE mid-block attention, 1 head x 512 channels) */
+int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, int32_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (32 groups in SD) over NHWC activations, optionally over the channel-concat of two
+ * tensors, fused with SiLU.  Replaces nn.GroupNorm + F.silu in ResnetBlock2D / Transformer2DModel.
+ *   stats: partial (sum, sumsq) per (image, split, group) -> `partials` [nimg][splits][groups][2]
+ *   apply: finalises mean/rstd from the partials and writes bf16 y = act((x-mean)*rstd*g + b)
+ * ------------------------------------------------------------------------------------------ */
+int sdv_groupnorm_stats(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
+                        int32_t HW, int32_t groups, int32_t splits, float* partials, void* stream);
+int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
+                        int32_t HW, int32_t groups, int32_t splits, const float* partials,
+                        const float* gamma, const float* beta, float eps, int32_t silu, sdv_bf16* Y,
+                        void* stream);
+
+/* LayerNorm over the last dim of [rows][C] bf16 (BasicTransformerBlock.norm1/2/3) */
+int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta, float eps, int64_t rows,
+                       int32_t C, sdv_bf16* Y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small-channel direct convolutions (no MFMA: K or N too small for a tile).
+ *   conv3x3_cin_small : Cin <= 8  (UNet conv_in 4->320, VAE decoder.conv_in 4->512), bf16 NHWC out
+ *   conv3x3_cout_small: Cout <= 4 (UNet conv_out 320->4 -> fp32 eps; VAE conv_out 128->3 -> image)
+ *     out_mode 0: fp32 NHWC out_f32 = conv + bias
+ *     out_mode 1: image epilogue of stable_diffusion_pipeline.py:435-438 + numpy_to_pil (:450):
+ *                 img = clamp(v/2+0.5, 0, 1) -> out_f32 (optional, fp32 NHWC) and
+ *                 out_u8 = rint(img*255) (round-half-even) uint8 NHWC
+ * ------------------------------------------------------------------------------------------ */
+int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Cin]*/, const float* bias,
+                          sdv_bf16* Y, int32_t nimg, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
+                          int32_t circular, void* stream);
+int sdv_conv3x3_cout_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Cin]*/, const float* bias,
+                           float* out_f32, uint8_t* out_u8, int32_t nimg, int32_t H, int32_t Wd,
+                           int32_t Cin, int32_t Cout, int32_t out_mode, int32_t circular, void* stream);
+
+/* z = Wpq * (x * in_scale) + b per pixel, fp32 NHWC latents -> bf16 NHWC (1/0.18215 scaling of
+ * stable_diffusion_pipeline.py:432 fused with AutoencoderKL.post_quant_conv) */
+int sdv_latent_affine(const float* X, const float* Wpq /*[C][C]*/, const float* bias, float in_scale,
+                      sdv_bf16* Y, int64_t npix, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Interpolation between walk endpoints (stable_diffusion_pipeline.py:466-468).
+ *   slerp_stats: dot(v0,v1), |v0|^2, |v1|^2 over the WHOLE tensor (utils.py:51) -> stats[3] (fp64)
+ *   slerp_batch: out[f] = slerp(T[f], v0, v1) for all frames f in one launch (utils.py:52-61);
+ *                input is CHW fp32; output is written HWC (NHWC latents) when to_hwc != 0.
+ *   lerp_batch : out[f] = torch.lerp(a, b, T[f]) (:467); fp32 in, bf16 and/or fp32 out.
+ * T is a device array of fp32.
+ * ------------------------------------------------------------------------------------------ */
+int sdv_slerp_stats(const float* v0, const float* v1, int64_t n, double* stats, void* stream);
+int sdv_slerp_batch(const float* v0, const float* v1, const double* stats, const float* T, int32_t nframes,
+                    int32_t C, int32_t HW, int32_t to_hwc, float dot_threshold, float* out, void* stream);
+int sdv_lerp_batch(const float* a, const float* b, const float* T, int32_t nframes, int64_t n,
+                   float* out_f32, sdv_bf16* out_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One fused classifier-free-guidance + DDIM update (stable_diffusion_pipeline.py:414, 422-426):
+ *     eps = eps_u + g (eps_c - eps_u);  x <- c_x * x + c_e * eps (+ sigma * noise)
+ * coefs is a device table [nsteps][4] = {c_x, c_e, sigma, unused}; the row is *step_ptr.  For
+ * v-prediction the host folds the conversion into a 2x2 per-step matrix (vpred != 0 -> coefs rows
+ * are {c_xx, c_xv, sigma, 0}); same arithmetic.  Also writes the NEXT UNet input: bf16 copies of
+ * the new latents for both CFG halves (x2[0:B] = x2[B:2B] = x) - the torch.cat([latents]*2) of :414.
+ * eps layout [2B][HW][C] fp32 (uncond first) when cfg != 0, else [B][HW][C].
+ * ------------------------------------------------------------------------------------------ */
+int sdv_cfg_ddim_step(const float* eps, float* latents, sdv_bf16* x2, const float* coefs,
+                      const int32_t* step_ptr, const float* noise, float guidance, int32_t cfg,
+                      int64_t n_per_batch /* B*HW*C */, void* stream);
+/* latents fp32 -> bf16 UNet input (both CFG halves); used once before step 0 */
+int sdv_latents_to_unet_input(const float* latents, sdv_bf16* x2, int32_t cfg, int64_t n, void* stream);
+int sdv_step_counter_add(int32_t* step_ptr, int32_t inc, void* stream);
+
+/* sinusoidal timestep embedding (diffusers get_timestep_embedding, flip_sin_to_cos) -> fp32 [n][dim] */
+int sdv_timestep_embedding(const float* timesteps, int32_t n, int32_t dim, int32_t flip_sin_to_cos,
+                           float freq_shift, float* out, void* stream);
+/* small fp32 linear: out[m][n] = sum_k act(x[m][k]) * w[n][k] + b[n] (+ add[n]); used once per
+ * walk for the time-embedding MLP and the 22 time_emb_proj tables (M = num_inference_steps). */
+int sdv_linear_small(const float* x, const sdv_bf16* w, const float* b, const float* add, float* out,
+                     int32_t M, int32_t N, int32_t K, int32_t silu_in, void* stream);
+
+/* layout helpers at the API boundary */
+int sdv_nchw_to_nhwc_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream);
+int sdv_nhwc_to_nchw_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream);
+int sdv_f32_to_bf16(const float* in, sdv_bf16* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDV_HIP_H */

@@ -1,0 +1,76 @@
+"""Build libsdv_hip.so (the gfx950 kernels behind the C ABI in include/sdv_hip.h) in-tree with hipcc.
+
+``python -m stable_diffusion_videos_amd.build [--force]``.  hipcc cross-compiles for gfx950 without a
+GPU; the resulting ``stable_diffusion_videos_amd/lib/libsdv_hip.so`` is git-ignored but travels with
+the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+INCLUDE = PKG.parent / "include"
+LIBDIR = PKG / "lib"
+OBJDIR = PKG / "lib" / "obj"
+LIB = LIBDIR / "libsdv_hip.so"
+ARCH = "gfx950"
+
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+         "-Wno-unused-result", "-I", str(INCLUDE)]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: cannot build libsdv_hip.so")
+    return exe
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _newest_dep() -> float:
+    deps = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    return max(p.stat().st_mtime for p in deps)
+
+
+def _compile(src: Path, force: bool) -> Path:
+    obj = OBJDIR / (src.stem + ".o")
+    if (not force and obj.exists() and obj.stat().st_mtime >= src.stat().st_mtime
+            and obj.stat().st_mtime >= _newest_dep()):
+        return obj
+    cmd = [hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    OBJDIR.mkdir(parents=True, exist_ok=True)
+    srcs = sources()
+    if not srcs:
+        raise RuntimeError(f"no .hip sources under {CSRC}")
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} ({LIB.stat().st_size >> 10} KiB) from {[s.name for s in srcs]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

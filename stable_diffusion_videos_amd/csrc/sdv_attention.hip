@@ -1,0 +1,301 @@
+// Flash-style attention for the UNet transformer blocks (self-attention, Lk = Lq in {4096,1024,256,64},
+// and text cross-attention, Lk = 77) on the gfx950 matrix cores.  Never materialises the Lq x Lk
+// score matrix - the reason the reference has to expose attention slicing
+// (/root/reference/.../stable_diffusion_pipeline.py:161-189).
+// Replaces CrossAttention.forward inside unet(...) (stable_diffusion_pipeline.py:418).
+//
+// Formulation ("swapped", so that everything per-query is lane-local):
+//   S^T[key][q] = K . Q^T      v_mfma_f32_32x32x16_bf16, A = K rows (LDS), B = Q rows (registers)
+//       -> lane l owns query q = l & 31 and 16 keys per 32-key subtile in its accumulator registers;
+//          the row max / row sum are register reductions plus ONE exchange with lane l^32.
+//   O^T[d][q]  = V^T . P^T     A = V^T rows (LDS, V is supplied transposed), B = P^T straight from the
+//       softmax registers (no cross-lane movement: the PV contraction may visit keys in any order as
+//       long as A and B agree, so the V^T tile is written to LDS in the MFMA C-layout key order).
+//   -> the running rescale O *= exp2(m_old - m_new) is also lane-local.
+// One workgroup = 4 waves x 32 queries = 128 queries of one head; K / V^T tiles of 64 keys are
+// register-staged (global -> VGPR issued before the MFMA phase, VGPR -> LDS after the barrier).
+// Head sizes: dh = 40 (K padded to 48 for QK^T, to 64 rows for PV), 64, 80 (96 rows for PV), 160.
+#include "sdv_common.h"
+
+namespace {
+
+template <int DH>
+struct AttnCfg {
+    static constexpr int DKS = (DH + 15) / 16;        // 16-wide k-steps of Q.K^T
+    static constexpr int DKP = DKS * 16;              // padded head dim for Q.K^T
+    static constexpr int DVT = (DH + 31) / 32;        // 32-row tiles of O^T
+    static constexpr int DVP = DVT * 32;
+    static constexpr int KROW = DKP * 2 + 16;         // LDS row stride of the K tile (odd # of 16-B slots)
+    static constexpr int VROW = 64 * 2 + 16;          // LDS row stride of the V^T tile (64 keys)
+    static constexpr int K_BYTES = 64 * KROW;
+    static constexpr int V_BYTES = DVP * VROW;
+    static constexpr int CPR = DH / 8;                // 16-B chunks per K row
+    static constexpr int KCH = 64 * CPR;              // chunks per K tile
+    static constexpr int VCH = DH * 8;                // chunks per V^T tile
+    static constexpr int KPT = (KCH + 255) / 256;     // chunks per thread
+    static constexpr int VPT = (VCH + 255) / 256;
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
+                                                        const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
+                                                        int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                                                        float scale_log2e) {
+    using Cfg = AttnCfg<DH>;
+    constexpr int DKS = Cfg::DKS, DVT = Cfg::DVT, KROW = Cfg::KROW, VROW = Cfg::VROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsK = smem;
+    char* ldsV = smem + Cfg::K_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // zero the LDS pads once: K columns [DH, DKP) and V^T rows [DH, DVP) are never rewritten
+    for (int i = tid; i < (Cfg::K_BYTES + Cfg::V_BYTES) / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+
+    // ---- Q fragments (B operand): lane owns query row q0 + l31, d = ks*16 + lhi*8 .. +7 ----
+    bf16x8_t qf[DKS];
+    {
+        int q = q0 + l31;
+        q = q < Lq ? q : Lq - 1;
+        const uint16_t* qrow = Q + ((long long)b * Lq + q) * ldq + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < DKS; ++ks) {
+            const int d0 = ks * 16 + lhi * 8;
+            if (d0 < DH)
+                qf[ks] = *(const bf16x8_t*)(qrow + d0);
+            else
+                qf[ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    // ---- register staging of the next K / V^T tile --------------------------------------------
+    u32x4_t kreg[Cfg::KPT], vreg[Cfg::VPT];
+    const uint16_t* Kb = Kp + (long long)b * Lk * ldk + h * DH;
+    const uint16_t* Vb = Vt + ((long long)b * H + h) * DH * ldv;
+    // (chunk indices are clamped instead of predicated: surplus threads re-load / re-store the last
+    //  chunk with identical data, which keeps the staging registers free of divergent control flow)
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < Cfg::KPT; ++i) {
+            int c = tid + i * 256;
+            c = c < Cfg::KCH ? c : Cfg::KCH - 1;
+            const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
+            int key = kv0 + row;
+            key = key < Lk ? key : Lk - 1;
+            kreg[i] = *(const u32x4_t*)(Kb + (long long)key * ldk + cc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::VPT; ++i) {
+            int c = tid + i * 256;
+            c = c < Cfg::VCH ? c : Cfg::VCH - 1;
+            const int row = c >> 3, cc = c & 7;
+            vreg[i] = *(const u32x4_t*)(Vb + (long long)row * ldv + kv0 + cc * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < Cfg::KPT; ++i) {
+            int c = tid + i * 256;
+            c = c < Cfg::KCH ? c : Cfg::KCH - 1;
+            const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
+            *(u32x4_t*)(ldsK + row * KROW + cc * 16) = kreg[i];
+        }
+        // V^T row d holds 64 keys; within each 16-key block the 4-key groups are stored in the order
+        // [0-3][8-11][4-7][12-15] so that one ds_read_b128 at (block*16 + lhi*8) keys yields exactly
+        // the keys this lane's P registers hold (MFMA 32x32 C-layout: key = (r&3) + 8*(r>>2) + 4*lhi).
+#pragma unroll
+        for (int i = 0; i < Cfg::VPT; ++i) {
+            int c = tid + i * 256;
+            c = c < Cfg::VCH ? c : Cfg::VCH - 1;
+            const int row = c >> 3, cc = c & 7;  // cc: 8-key chunk; block = cc>>1, half = cc&1
+            char* dst = ldsV + row * VROW + (cc >> 1) * 32 + (cc & 1) * 8;
+            *(u32x2_t*)(dst) = u32x2_t{vreg[i][0], vreg[i][1]};        // keys +0..3
+            *(u32x2_t*)(dst + 16) = u32x2_t{vreg[i][2], vreg[i][3]};   // keys +4..7
+        }
+    };
+
+    f32x16_t o[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;  // this lane's partial row sum (its 32 of the 64 keys per tile)
+
+    const int ntiles = (Lk + 63) / 64;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();  // previous tile fully consumed (and the pad zeroing is visible)
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile((t + 1) * 64);
+
+        // ---- S^T = K . Q^T for two 32-key subtiles ----
+        f32x16_t s[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[j][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < DKS; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(ldsK + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
+                s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (base-2), lane-local ----
+        const int kv0 = t * 64;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = s[j][r] * scale_log2e;
+                v = key < Lk ? v : -INFINITY;
+                s[j][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    pv[e] = __builtin_amdgcn_exp2f(s[j][8 * u + e] - m_new);
+                    psum += pv[e];
+                }
+                u32x4_t pr;
+                pr[0] = pack_bf16x2(pv[0], pv[1]);
+                pr[1] = pack_bf16x2(pv[2], pv[3]);
+                pr[2] = pack_bf16x2(pv[4], pv[5]);
+                pr[3] = pack_bf16x2(pv[6], pv[7]);
+                pf[j * 2 + u] = __builtin_bit_cast(bf16x8_t, pr);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+            for (int ju = 0; ju < 4; ++ju) {
+                const bf16x8_t vf = *(const bf16x8_t*)(ldsV + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ju], o[dt], 0, 0, 0);
+            }
+    }
+
+    // ---- normalise and store O[q][h*DH + d] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < Lq) {
+        uint16_t* orow = O + ((long long)b * Lq + q) * ldo + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = dt * 32 + 8 * g4 + 4 * lhi;
+                if (d < DH) {
+                    uint2 w;
+                    w.x = pack_bf16x2(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
+                    w.y = pack_bf16x2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                    *(uint2*)(orow + d) = w;
+                }
+            }
+    }
+}
+
+template <int DH>
+int launch_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
+                     int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+    using Cfg = AttnCfg<DH>;
+    dim3 grid((Lq + 127) / 128, H, B);
+    const int lds = Cfg::K_BYTES + Cfg::V_BYTES;
+    hipLaunchKernelGGL((attention_kernel<DH>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
+                       scale * 1.4426950408889634f);
+    SDV_CHECK_LAUNCH("sdv_attention_bf16");
+    return SDV_OK;
+}
+
+// ---- in-place row softmax over bf16 (VAE mid-block attention scores) -------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(uint16_t* __restrict__ S, int cols, int ld) {
+    __shared__ float red[8];
+    uint16_t* row = S + (long long)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        const bf16x8_raw r = *(const bf16x8_raw*)(row + c);
+        float f[8];
+        unpack8(r, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[e]);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        const bf16x8_raw r = *(const bf16x8_raw*)(row + c);
+        float f[8];
+        unpack8(r, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __expf(f[e] - mx);
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        const bf16x8_raw r = *(const bf16x8_raw*)(row + c);
+        float f[8];
+        unpack8(r, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = __expf(f[e] - mx) * inv;
+        *(bf16x8_raw*)(row + c) = pack8(f);
+    }
+}
+
+}  // namespace
+
+extern "C" int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O, int32_t B,
+                                  int32_t H, int32_t Lq, int32_t Lk, int32_t dh, int32_t ldq, int32_t ldk, int32_t ldv,
+                                  int32_t ldo, float scale, void* stream) {
+    SDV_REQUIRE(Q && K && Vt && O, "sdv_attention_bf16: null pointer");
+    SDV_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sdv_attention_bf16: bad shape");
+    SDV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sdv_attention_bf16: unaligned leading dims");
+    SDV_REQUIRE(ldv >= ((Lk + 63) / 64) * 64, "sdv_attention_bf16: ldv=%d must cover roundup(Lk=%d, 64)", ldv, Lk);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {
+        case 40: return launch_attention<40>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+        case 64: return launch_attention<64>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+        case 80: return launch_attention<80>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+        case 160: return launch_attention<160>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+        default: SDV_REQUIRE(false, "sdv_attention_bf16: unsupported head dim %d (40/64/80/160)", dh);
+    }
+    return SDV_OK;
+}
+
+extern "C" int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, int32_t ld, void* stream) {
+    SDV_REQUIRE(S && rows > 0 && cols > 0, "sdv_softmax_rows_bf16: bad args");
+    SDV_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "sdv_softmax_rows_bf16: cols/ld must be multiples of 8");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, cols, ld);
+    SDV_CHECK_LAUNCH("sdv_softmax_rows_bf16");
+    return SDV_OK;
+}

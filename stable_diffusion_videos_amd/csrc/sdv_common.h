@@ -1,0 +1,81 @@
+// Internal helpers shared by the gfx950 kernels of libsdv_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sdv_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = 4 VGPRs (MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 4 bf16 = 8 bytes
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define SDV_DEVICE __device__ __forceinline__
+
+// ---- bf16 <-> fp32 (round-to-nearest-even, NaN preserved) ------------------------------------
+SDV_DEVICE float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+SDV_DEVICE uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+SDV_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+SDV_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+SDV_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 16-byte vector of 8 bf16 <-> 8 floats
+struct alignas(16) bf16x8_raw { uint32_t w[4]; };
+SDV_DEVICE void unpack8(const bf16x8_raw& r, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(r.w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(r.w[i] & 0xffff0000u);
+    }
+}
+SDV_DEVICE bf16x8_raw pack8(const float* f) {
+    bf16x8_raw r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return r;
+}
+
+// ---- async global -> LDS copy (16 B per lane, LDS destination = wave-uniform base + lane*16) ---
+SDV_DEVICE void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+SDV_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+SDV_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- host side error plumbing ------------------------------------------------------------------
+void sdv_set_error(const char* fmt, ...);
+#define SDV_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            sdv_set_error(__VA_ARGS__);   \
+            return SDV_ERR_ARG;           \
+        }                                 \
+    } while (0)
+#define SDV_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            sdv_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return SDV_ERR_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)

@@ -1,0 +1,513 @@
+// Wave-level elementwise / small kernels of the walk hot path: endpoint interpolation (lerp / slerp),
+// the fused classifier-free-guidance + DDIM update, timestep embedding, the tiny fp32 linear used for
+// the per-walk time-embedding tables, layout helpers, and the small-channel direct convolutions
+// (UNet conv_in / conv_out, VAE conv_in / conv_out with the image epilogue).
+#include <stdarg.h>
+
+#include "sdv_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void sdv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sdv_last_error(void) { return g_err; }
+extern "C" int sdv_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned grid_for(long long n, int per_block = kThreads, long long cap = 16384) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ---- slerp: whole-tensor reductions (utils.py:51) -----------------------------------------------
+__global__ __launch_bounds__(1024) void slerp_stats_kernel(const float* __restrict__ v0, const float* __restrict__ v1,
+                                                           long long n, double* __restrict__ stats) {
+    __shared__ double red[3][16];
+    double d = 0, a = 0, b = 0;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const double x = v0[i], y = v1[i];
+        d += x * y;
+        a += x * x;
+        b += y * y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        d += __shfl_xor(d, o);
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][w] = d;
+        red[1][w] = a;
+        red[2][w] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0;
+        for (int i = 0; i < 16; ++i) s += red[threadIdx.x][i];
+        stats[threadIdx.x] = s;
+    }
+}
+
+// out[f] = s0(f) * v0 + s1(f) * v1   (utils.py:52-61); grid.y = frame
+__global__ __launch_bounds__(kThreads) void slerp_batch_kernel(const float* __restrict__ v0, const float* __restrict__ v1,
+                                                               const double* __restrict__ stats,
+                                                               const float* __restrict__ T, int C, int HW, int to_hwc,
+                                                               float dot_threshold, float* __restrict__ out) {
+    const int f = blockIdx.y;
+    const float t = T[f];
+    // the reference computes these in the tensor dtype (fp32); the reductions here are fp64
+    const float dot = (float)(stats[0] / (sqrt(stats[1]) * sqrt(stats[2])));
+    float s0, s1;
+    if (fabsf(dot) > dot_threshold) {
+        s0 = 1.0f - t;
+        s1 = t;
+    } else {
+        const float theta0 = acosf(dot);
+        const float sin0 = sinf(theta0);
+        const float theta_t = theta0 * t;
+        s0 = sinf(theta0 - theta_t) / sin0;
+        s1 = sinf(theta_t) / sin0;
+    }
+    const long long n = (long long)C * HW;
+    float* o = out + (long long)f * n;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const float v = s0 * v0[i] + s1 * v1[i];
+        if (to_hwc) {
+            const int c = (int)(i / HW);
+            const int p = (int)(i - (long long)c * HW);
+            o[(long long)p * C + c] = v;
+        } else {
+            o[i] = v;
+        }
+    }
+}
+
+// torch.lerp: weight < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
+__global__ __launch_bounds__(kThreads) void lerp_batch_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ T, long long n,
+                                                              float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
+    const int f = blockIdx.y;
+    const float w = T[f];
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const float x = a[i], y = b[i];
+        const float d = y - x;
+        const float v = w < 0.5f ? x + w * d : y - d * (1.0f - w);
+        if (out_f32) out_f32[(long long)f * n + i] = v;
+        if (out_bf16) out_bf16[(long long)f * n + i] = f32_to_bf16(v);
+    }
+}
+
+// ---- CFG + DDIM ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void cfg_ddim_kernel(const float* __restrict__ eps, float* __restrict__ latents,
+                                                            uint16_t* __restrict__ x2, const float* __restrict__ coefs,
+                                                            const int* __restrict__ step_ptr,
+                                                            const float* __restrict__ noise, float guidance, int cfg,
+                                                            long long n) {
+    const int step = step_ptr ? *step_ptr : 0;
+    const float cx = coefs[step * 4 + 0], ce = coefs[step * 4 + 1], sg = coefs[step * 4 + 2];
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        float e;
+        if (cfg) {
+            const float eu = eps[i], ec = eps[n + i];
+            e = eu + guidance * (ec - eu);
+        } else {
+            e = eps[i];
+        }
+        float x = cx * latents[i] + ce * e;
+        if (noise) x += sg * noise[(long long)step * n + i];
+        latents[i] = x;
+        const uint16_t xb = f32_to_bf16(x);
+        x2[i] = xb;
+        if (cfg) x2[n + i] = xb;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void latents_to_input_kernel(const float* __restrict__ latents,
+                                                                    uint16_t* __restrict__ x2, int cfg, long long n) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const uint16_t xb = f32_to_bf16(latents[i]);
+        x2[i] = xb;
+        if (cfg) x2[n + i] = xb;
+    }
+}
+
+__global__ void step_add_kernel(int* p, int inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p += inc;
+}
+
+// ---- timestep embedding ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void timestep_embedding_kernel(const float* __restrict__ ts, int n, int dim,
+                                                                      int flip, float freq_shift,
+                                                                      float* __restrict__ out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n * half) return;
+    const int r = i / half, k = i - r * half;
+    // once-per-walk kernel: the frequency is evaluated in fp64, the product is rounded to fp32 exactly as
+    // diffusers does (t.float() * exp(exponent).float()) and sin/cos are taken in fp64 of that fp32 argument
+    const float freq = (float)exp(-9.210340371976184 * (double)k / ((double)half - (double)freq_shift));  // ln(10000)
+    const float a = ts[r] * freq;
+    const float s = (float)sin((double)a), c = (float)cos((double)a);
+    float* o = out + (long long)r * dim;
+    if (flip) {
+        o[k] = c;
+        o[half + k] = s;
+    } else {
+        o[k] = s;
+        o[half + k] = c;
+    }
+}
+
+// out[m][n] = sum_k act(x[m][k]) w[n][k] + b[n] + add[n]; one wave per output element row-pair
+__global__ __launch_bounds__(kThreads) void linear_small_kernel(const float* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                const float* __restrict__ b, const float* __restrict__ add,
+                                                                float* __restrict__ out, int M, int N, int K, int silu_in) {
+    const int lane = threadIdx.x & 63;
+    const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (long long)M * N) return;
+    const int m = (int)(o / N), n = (int)(o - (long long)m * N);
+    const float* xr = x + (long long)m * K;
+    const uint16_t* wr = w + (long long)n * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float xv = xr[k];
+        if (silu_in) xv = silu_f(xv);
+        acc += xv * bf16_to_f32(wr[k]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[o] = acc + (b ? b[n] : 0.f) + (add ? add[n] : 0.f);
+}
+
+// ---- layout helpers -------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void permute_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int n, int C, int HW, int to_nhwc) {
+    const long long tot = (long long)n * C * HW;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < tot; i += (long long)gridDim.x * kThreads) {
+        // i indexes the OUTPUT
+        const long long per = (long long)C * HW;
+        const long long img = i / per, r = i - img * per;
+        if (to_nhwc) {
+            const int p = (int)(r / C), c = (int)(r - (long long)p * C);
+            out[i] = in[img * per + (long long)c * HW + p];
+        } else {
+            const int c = (int)(r / HW), p = (int)(r - (long long)c * HW);
+            out[i] = in[img * per + (long long)p * C + c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void f32_to_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
+                                                               long long n) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+        out[i] = f32_to_bf16(in[i]);
+}
+
+// z[p][o] = sum_c Wpq[o][c] * (x[p][c] * in_scale) + b[o]      (C <= 8)
+__global__ __launch_bounds__(kThreads) void latent_affine_kernel(const float* __restrict__ X, const float* __restrict__ Wpq,
+                                                                 const float* __restrict__ bias, float in_scale,
+                                                                 uint16_t* __restrict__ Y, long long npix, int C) {
+    for (long long p = (long long)blockIdx.x * kThreads + threadIdx.x; p < npix; p += (long long)gridDim.x * kThreads) {
+        float xin[8];
+        for (int c = 0; c < C; ++c) xin[c] = X[p * C + c] * in_scale;
+        for (int o = 0; o < C; ++o) {
+            float a = bias ? bias[o] : 0.f;
+            for (int c = 0; c < C; ++c) a += Wpq[o * C + c] * xin[c];
+            Y[p * C + o] = f32_to_bf16(a);
+        }
+    }
+}
+
+// ---- direct conv3x3, tiny Cin (4 -> 320 / 512): thread = (pixel, 8 output channels) ------------
+// weights [Cout][9][Cin] bf16 are transposed into LDS as fp32 [9*Cin][Cout] once per block.
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void conv3x3_cin_small_kernel(const uint16_t* __restrict__ X,
+                                                                     const uint16_t* __restrict__ Wt,
+                                                                     const float* __restrict__ bias,
+                                                                     uint16_t* __restrict__ Y, int nimg, int H, int Wd,
+                                                                     int Cout, int circular) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wl = (float*)smem_raw;  // [9*CIN][Cout]
+    constexpr int KK = 9 * CIN;
+    for (int i = threadIdx.x; i < KK * Cout; i += kThreads) {
+        const int co = i / KK, k = i - co * KK;
+        wl[k * Cout + co] = bf16_to_f32(Wt[i]);
+    }
+    __syncthreads();
+    const int cgroups = Cout >> 3;                  // 8-channel groups per pixel
+    const long long npix = (long long)nimg * H * Wd;
+    const long long total = npix * cgroups;
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const long long pix = idx / cgroups;
+        const int cg = (int)(idx - pix * cgroups);
+        const int img = (int)(pix / ((long long)H * Wd));
+        const int rem = (int)(pix - (long long)img * H * Wd);
+        const int y = rem / Wd, x = rem - y * Wd;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[cg * 8 + e] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            bool ok = true;
+            if (circular) {
+                iy = (iy + H) % H;
+                ix = (ix + Wd) % Wd;
+            } else {
+                ok = iy >= 0 && iy < H && ix >= 0 && ix < Wd;
+            }
+            if (!ok) continue;
+            const uint16_t* xp = X + (((long long)img * H + iy) * Wd + ix) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float xv = bf16_to_f32(xp[c]);
+                const float* wrow = wl + (tap * CIN + c) * Cout + cg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += xv * wrow[e];
+            }
+        }
+        *(bf16x8_raw*)(Y + pix * Cout + cg * 8) = pack8(acc);
+    }
+}
+
+// ---- direct conv3x3, tiny Cout (<= 4): one wave per output pixel, lanes split the 9*Cin reduction ----
+template <int COUT>
+__global__ __launch_bounds__(kThreads) void conv3x3_cout_small_kernel(const uint16_t* __restrict__ X,
+                                                                      const uint16_t* __restrict__ Wt,
+                                                                      const float* __restrict__ bias,
+                                                                      float* __restrict__ out_f32,
+                                                                      uint8_t* __restrict__ out_u8, int nimg, int H,
+                                                                      int Wd, int Cin, int out_mode, int circular) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint16_t* wl = (uint16_t*)smem_raw;  // [COUT][9][Cin] bf16 copy
+    const int wn = COUT * 9 * Cin;
+    for (int i = threadIdx.x * 8; i < wn; i += kThreads * 8) *(uint4*)(wl + i) = *(const uint4*)(Wt + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cchunks = Cin >> 3;        // 16-B chunks per pixel
+    const int nwork = 9 * cchunks;       // (tap, chunk) pairs, split over lanes
+    const long long npix = (long long)nimg * H * Wd;
+    for (long long pix = (long long)blockIdx.x * 4 + wave; pix < npix; pix += (long long)gridDim.x * 4) {
+        const int img = (int)(pix / ((long long)H * Wd));
+        const int rem = (int)(pix - (long long)img * H * Wd);
+        const int y = rem / Wd, x = rem - y * Wd;
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        for (int wk = lane; wk < nwork; wk += 64) {
+            const int tap = wk / cchunks, ch = wk - tap * cchunks;
+            int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            if (circular) {
+                iy = (iy + H) % H;
+                ix = (ix + Wd) % Wd;
+            } else if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) {
+                continue;
+            }
+            const bf16x8_raw xr = *(const bf16x8_raw*)(X + (((long long)img * H + iy) * Wd + ix) * Cin + ch * 8);
+            float xf[8];
+            unpack8(xr, xf);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const bf16x8_raw wr = *(const bf16x8_raw*)(wl + (o * 9 + tap) * Cin + ch * 8);
+                float wf[8];
+                unpack8(wr, wf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o] += xf[e] * wf[e];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = wave_sum(acc[o]);
+        if (lane == 0) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                float v = acc[o] + (bias ? bias[o] : 0.f);
+                if (out_mode == 0) {
+                    out_f32[pix * COUT + o] = v;
+                } else {
+                    v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);
+                    if (out_f32) out_f32[pix * COUT + o] = v;
+                    if (out_u8) out_u8[pix * COUT + o] = (uint8_t)rintf(v * 255.0f);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int sdv_slerp_stats(const float* v0, const float* v1, int64_t n, double* stats, void* stream) {
+    SDV_REQUIRE(v0 && v1 && stats && n > 0, "sdv_slerp_stats: bad args");
+    hipLaunchKernelGGL(slerp_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v0, v1, (long long)n, stats);
+    SDV_CHECK_LAUNCH("sdv_slerp_stats");
+    return SDV_OK;
+}
+
+extern "C" int sdv_slerp_batch(const float* v0, const float* v1, const double* stats, const float* T, int32_t nframes,
+                               int32_t C, int32_t HW, int32_t to_hwc, float dot_threshold, float* out, void* stream) {
+    SDV_REQUIRE(v0 && v1 && stats && T && out, "sdv_slerp_batch: null pointer");
+    SDV_REQUIRE(nframes > 0 && C > 0 && HW > 0, "sdv_slerp_batch: bad sizes");
+    const long long n = (long long)C * HW;
+    hipLaunchKernelGGL(slerp_batch_kernel, dim3(grid_for(n, kThreads, 256), nframes), dim3(kThreads), 0,
+                       (hipStream_t)stream, v0, v1, stats, T, C, HW, to_hwc, dot_threshold, out);
+    SDV_CHECK_LAUNCH("sdv_slerp_batch");
+    return SDV_OK;
+}
+
+extern "C" int sdv_lerp_batch(const float* a, const float* b, const float* T, int32_t nframes, int64_t n, float* out_f32,
+                              sdv_bf16* out_bf16, void* stream) {
+    SDV_REQUIRE(a && b && T && (out_f32 || out_bf16), "sdv_lerp_batch: null pointer");
+    SDV_REQUIRE(nframes > 0 && n > 0, "sdv_lerp_batch: bad sizes");
+    hipLaunchKernelGGL(lerp_batch_kernel, dim3(grid_for(n, kThreads, 256), nframes), dim3(kThreads), 0,
+                       (hipStream_t)stream, a, b, T, (long long)n, out_f32, out_bf16);
+    SDV_CHECK_LAUNCH("sdv_lerp_batch");
+    return SDV_OK;
+}
+
+extern "C" int sdv_cfg_ddim_step(const float* eps, float* latents, sdv_bf16* x2, const float* coefs,
+                                 const int32_t* step_ptr, const float* noise, float guidance, int32_t cfg,
+                                 int64_t n_per_batch, void* stream) {
+    SDV_REQUIRE(eps && latents && x2 && coefs && n_per_batch > 0, "sdv_cfg_ddim_step: bad args");
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n_per_batch, kThreads, 2048)), dim3(kThreads), 0,
+                       (hipStream_t)stream, eps, latents, x2, coefs, step_ptr, noise, guidance, cfg, (long long)n_per_batch);
+    SDV_CHECK_LAUNCH("sdv_cfg_ddim_step");
+    return SDV_OK;
+}
+
+extern "C" int sdv_latents_to_unet_input(const float* latents, sdv_bf16* x2, int32_t cfg, int64_t n, void* stream) {
+    SDV_REQUIRE(latents && x2 && n > 0, "sdv_latents_to_unet_input: bad args");
+    hipLaunchKernelGGL(latents_to_input_kernel, dim3(grid_for(n, kThreads, 2048)), dim3(kThreads), 0, (hipStream_t)stream,
+                       latents, x2, cfg, (long long)n);
+    SDV_CHECK_LAUNCH("sdv_latents_to_unet_input");
+    return SDV_OK;
+}
+
+extern "C" int sdv_step_counter_add(int32_t* step_ptr, int32_t inc, void* stream) {
+    SDV_REQUIRE(step_ptr, "sdv_step_counter_add: null pointer");
+    hipLaunchKernelGGL(step_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr, inc);
+    SDV_CHECK_LAUNCH("sdv_step_counter_add");
+    return SDV_OK;
+}
+
+extern "C" int sdv_timestep_embedding(const float* timesteps, int32_t n, int32_t dim, int32_t flip_sin_to_cos,
+                                      float freq_shift, float* out, void* stream) {
+    SDV_REQUIRE(timesteps && out && n > 0 && dim > 0 && dim % 2 == 0, "sdv_timestep_embedding: bad args");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((long long)n * dim / 2)), dim3(kThreads), 0,
+                       (hipStream_t)stream, timesteps, n, dim, flip_sin_to_cos, freq_shift, out);
+    SDV_CHECK_LAUNCH("sdv_timestep_embedding");
+    return SDV_OK;
+}
+
+extern "C" int sdv_linear_small(const float* x, const sdv_bf16* w, const float* b, const float* add, float* out, int32_t M,
+                                int32_t N, int32_t K, int32_t silu_in, void* stream) {
+    SDV_REQUIRE(x && w && out && M > 0 && N > 0 && K > 0, "sdv_linear_small: bad args");
+    const long long outs = (long long)M * N;
+    hipLaunchKernelGGL(linear_small_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, x, w,
+                       b, add, out, M, N, K, silu_in);
+    SDV_CHECK_LAUNCH("sdv_linear_small");
+    return SDV_OK;
+}
+
+extern "C" int sdv_nchw_to_nhwc_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream) {
+    SDV_REQUIRE(in && out && n > 0 && C > 0 && HW > 0, "sdv_nchw_to_nhwc_f32: bad args");
+    hipLaunchKernelGGL(permute_f32_kernel, dim3(grid_for((long long)n * C * HW)), dim3(kThreads), 0, (hipStream_t)stream,
+                       in, out, n, C, HW, 1);
+    SDV_CHECK_LAUNCH("sdv_nchw_to_nhwc_f32");
+    return SDV_OK;
+}
+
+extern "C" int sdv_nhwc_to_nchw_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream) {
+    SDV_REQUIRE(in && out && n > 0 && C > 0 && HW > 0, "sdv_nhwc_to_nchw_f32: bad args");
+    hipLaunchKernelGGL(permute_f32_kernel, dim3(grid_for((long long)n * C * HW)), dim3(kThreads), 0, (hipStream_t)stream,
+                       in, out, n, C, HW, 0);
+    SDV_CHECK_LAUNCH("sdv_nhwc_to_nchw_f32");
+    return SDV_OK;
+}
+
+extern "C" int sdv_f32_to_bf16(const float* in, sdv_bf16* out, int64_t n, void* stream) {
+    SDV_REQUIRE(in && out && n > 0, "sdv_f32_to_bf16: bad args");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, in, out, (long long)n);
+    SDV_CHECK_LAUNCH("sdv_f32_to_bf16");
+    return SDV_OK;
+}
+
+extern "C" int sdv_latent_affine(const float* X, const float* Wpq, const float* bias, float in_scale, sdv_bf16* Y,
+                                 int64_t npix, int32_t C, void* stream) {
+    SDV_REQUIRE(X && Wpq && Y && npix > 0 && C > 0 && C <= 8, "sdv_latent_affine: bad args (C <= 8)");
+    hipLaunchKernelGGL(latent_affine_kernel, dim3(grid_for(npix)), dim3(kThreads), 0, (hipStream_t)stream, X, Wpq, bias,
+                       in_scale, Y, (long long)npix, C);
+    SDV_CHECK_LAUNCH("sdv_latent_affine");
+    return SDV_OK;
+}
+
+extern "C" int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W, const float* bias, sdv_bf16* Y, int32_t nimg,
+                                     int32_t H, int32_t Wd, int32_t Cin, int32_t Cout, int32_t circular, void* stream) {
+    SDV_REQUIRE(X && W && Y, "sdv_conv3x3_cin_small: null pointer");
+    SDV_REQUIRE(Cin == 4 || Cin == 8, "sdv_conv3x3_cin_small: Cin must be 4 or 8 (got %d)", Cin);
+    SDV_REQUIRE(Cout % 8 == 0 && Cout > 0, "sdv_conv3x3_cin_small: Cout must be a multiple of 8");
+    const size_t lds = (size_t)9 * Cin * Cout * sizeof(float);
+    SDV_REQUIRE(lds <= 160 * 1024, "sdv_conv3x3_cin_small: weights do not fit LDS");
+    const long long total = (long long)nimg * H * Wd * (Cout / 8);
+    const unsigned grid = grid_for(total, kThreads, 4096);
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 4) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_cin_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv3x3_cin_small_kernel<4>, dim3(grid), dim3(kThreads), lds, s, X, W, bias, Y, nimg, H, Wd, Cout,
+                           circular);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_cin_small_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv3x3_cin_small_kernel<8>, dim3(grid), dim3(kThreads), lds, s, X, W, bias, Y, nimg, H, Wd, Cout,
+                           circular);
+    }
+    SDV_CHECK_LAUNCH("sdv_conv3x3_cin_small");
+    return SDV_OK;
+}
+
+extern "C" int sdv_conv3x3_cout_small(const sdv_bf16* X, const sdv_bf16* W, const float* bias, float* out_f32,
+                                      uint8_t* out_u8, int32_t nimg, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
+                                      int32_t out_mode, int32_t circular, void* stream) {
+    SDV_REQUIRE(X && W, "sdv_conv3x3_cout_small: null pointer");
+    SDV_REQUIRE(Cout >= 1 && Cout <= 4, "sdv_conv3x3_cout_small: Cout must be 1..4 (got %d)", Cout);
+    SDV_REQUIRE(Cin % 8 == 0 && Cin > 0, "sdv_conv3x3_cout_small: Cin must be a multiple of 8");
+    SDV_REQUIRE(out_mode == 0 ? out_f32 != nullptr : (out_f32 || out_u8), "sdv_conv3x3_cout_small: no output buffer");
+    const size_t lds = (size_t)Cout * 9 * Cin * 2;
+    SDV_REQUIRE(lds <= 64 * 1024, "sdv_conv3x3_cout_small: weights do not fit LDS");
+    const long long npix = (long long)nimg * H * Wd;
+    const unsigned grid = grid_for(npix, 4, 8192);
+    hipStream_t s = (hipStream_t)stream;
+#define SDV_LAUNCH_CO(CO)                                                                                           \
+    hipLaunchKernelGGL(conv3x3_cout_small_kernel<CO>, dim3(grid), dim3(kThreads), lds, s, X, W, bias, out_f32, out_u8, \
+                       nimg, H, Wd, Cin, out_mode, circular)
+    switch (Cout) {
+        case 1: SDV_LAUNCH_CO(1); break;
+        case 2: SDV_LAUNCH_CO(2); break;
+        case 3: SDV_LAUNCH_CO(3); break;
+        default: SDV_LAUNCH_CO(4); break;
+    }
+#undef SDV_LAUNCH_CO
+    SDV_CHECK_LAUNCH("sdv_conv3x3_cout_small");
+    return SDV_OK;
+}

@@ -1,0 +1,359 @@
+// Implicit-GEMM on the gfx950 bf16 matrix cores: dense GEMM, conv3x3 (stride 1 / stride 2 /
+// nearest-2x-upsample-then-conv) over NHWC activations, with the skip-connection concat, bias /
+// time-embedding bias table, residual add, SiLU and GEGLU fused into the kernel.
+//
+// Replaces the ATen->cuDNN/cuBLAS work dispatched by
+//   unet(x, t, encoder_hidden_states=ctx)      /root/reference/.../stable_diffusion_pipeline.py:418
+//   vae.decode(latents)                        /root/reference/.../stable_diffusion_pipeline.py:433
+//
+// Design (CDNA4):
+//   * C[m][n] = sum_k X[m][k] W[n][k].  Both operands are K-contiguous rows, so both are staged the
+//     same way: 64-wide K tiles (128 B per row) go HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA,
+//     no VGPR round trip), double buffered, ONE barrier per K tile, next tile in flight during MFMA.
+//   * LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied on the
+//     per-lane SOURCE address and again on the ds_read_b128: physical 16-B chunk = logical chunk ^
+//     ((row >> 1) & 7).  With 128-B rows two rows share a 256-B bank row, and this spreads any 16
+//     rows that are distinct mod 16 over all 16 slots -> conflict-free ds_read_b128 fragments.
+//   * v_mfma_f32_32x32x16_bf16 with the WEIGHT rows as the A operand and the ACTIVATION rows as the
+//     B operand: lane l then owns output row m = l & 31 and, per accumulator quad, 4 CONSECUTIVE
+//     output channels n -> 8-byte bf16 stores / residual loads and per-register bias.
+//   * conv3x3: the K loop walks (tap, channel-tile); the per-lane source address is the shifted /
+//     strided / upsampled pixel, and padding pixels are redirected to a 256-B zero page in HBM.
+#include "sdv_common.h"
+
+namespace {
+
+constexpr int kBK = 64;  // K tile (bf16 elements) = 128 bytes per row
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int ROWS = BM + BN;
+    constexpr int TILE_BYTES = ROWS * 128;
+    constexpr int NX = BM / 32;  // X rows staged per lane per K tile
+    constexpr int NW = BN / 32;  // W rows staged per lane per K tile
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int bm = blockIdx.x % tiles_m;
+    const int bn = blockIdx.x / tiles_m;
+    const int m0 = bm * BM;
+    const int n0 = bn * BN;
+    const long long bz = blockIdx.z;
+
+    const uint16_t* __restrict__ X = p.X + bz * p.sX;
+    const uint16_t* __restrict__ X2 = p.X2;
+    const uint16_t* __restrict__ W = p.W + bz * p.sW;
+    const int mode = p.mode;
+    const int K = p.K;
+
+    // ---- per-lane staging bookkeeping -------------------------------------------------------
+    const int rg = lane >> 3;  // row inside the 8-row group one wave-instruction moves
+    const int pc = lane & 7;   // physical 16-B chunk inside the 128-B LDS row
+    long long xa[NX], xb[NX];
+    int xoy[NX], xox[NX], xlc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int r = (wave + 4 * i) * 8 + rg;
+        int m = m0 + r;
+        m = m < p.M ? m : p.M - 1;
+        xlc[i] = (pc ^ ((r >> 1) & 7)) * 8;
+        if (mode == 0) {
+            xa[i] = (long long)m * p.ldx;
+            xb[i] = (long long)m * p.ldx2;
+            xoy[i] = 0;
+            xox[i] = 0;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int img = m / hw;
+            const int rem = m - img * hw;
+            const int oy = rem / p.Wout;
+            xa[i] = (long long)img * p.Hin * p.Win;
+            xb[i] = 0;
+            xoy[i] = oy;
+            xox[i] = rem - oy * p.Wout;
+        }
+    }
+    long long wa[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int r = (wave + 4 * (NX + i)) * 8 + rg;  // tile row (>= BM)
+        int n = n0 + (r - BM);
+        n = n < p.N ? n : p.N - 1;
+        wa[i] = (long long)n * p.ldw + (pc ^ ((r >> 1) & 7)) * 8;
+    }
+
+    auto stage = [&](int buf, int tap, int kc) {
+        char* base = smem + buf * TILE_BYTES;
+        const bool second = kc >= p.C1;
+        const uint16_t* src = second ? X2 : X;
+        const int ld = second ? p.ldx2 : p.ldx;
+        const int kcc = second ? kc - p.C1 : kc;
+        const int dy = tap / 3 - 1;
+        const int dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const uint16_t* g;
+            if (mode == 0) {
+                g = src + (second ? xb[i] : xa[i]) + kcc + xlc[i];
+            } else {
+                int iy, ix;
+                bool ok = true;
+                if (mode == 3) {  // conv over the nearest-2x upsampled image (Hout = 2*Hin)
+                    int uy = xoy[i] + dy, ux = xox[i] + dx;
+                    if (p.circular) {
+                        uy = uy < 0 ? uy + p.Hout : (uy >= p.Hout ? uy - p.Hout : uy);
+                        ux = ux < 0 ? ux + p.Wout : (ux >= p.Wout ? ux - p.Wout : ux);
+                    } else {
+                        ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
+                    }
+                    iy = uy >> 1;
+                    ix = ux >> 1;
+                } else {
+                    const int s = mode == 2 ? 2 : 1;
+                    iy = xoy[i] * s + dy;
+                    ix = xox[i] * s + dx;
+                    if (p.circular) {
+                        iy = iy < 0 ? iy + p.Hin : (iy >= p.Hin ? iy - p.Hin : iy);
+                        ix = ix < 0 ? ix + p.Win : (ix >= p.Win ? ix - p.Win : ix);
+                    } else {
+                        ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
+                    }
+                }
+                const long long pix = xa[i] + (long long)iy * p.Win + ix;
+                g = ok ? src + pix * ld + kcc + xlc[i] : p.zero_page + xlc[i];
+            }
+            glds16(g, base + (wave + 4 * i) * 1024);
+        }
+        const long long kw = (long long)tap * K + kc;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            glds16(W + wa[i] + kw, base + (wave + 4 * (NX + i)) * 1024);
+        }
+    };
+
+    f32x16_t acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+
+    auto compute = [&](int buf) {
+        const char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < kBK / 16; ++ks) {
+            bf16x8_t xf[TM], wf[TN];
+            const int lc = ks * 2 + lhi;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int r = wm * TM * 32 + mt * 32 + l31;
+                xf[mt] = *(const bf16x8_t*)(base + r * 128 + ((lc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int r = BM + wn * TN * 32 + nt * 32 + l31;
+                wf[nt] = *(const bf16x8_t*)(base + r * 128 + ((lc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
+    const int ntaps = mode == 0 ? 1 : 9;
+    const int nkt = (K / kBK) * ntaps;
+    int tap = 0, kc = 0;
+    stage(0, 0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        kc += kBK;
+        if (kc == K) {
+            kc = 0;
+            ++tap;
+        }
+        if (kt + 1 < nkt) stage((kt + 1) & 1, tap, kc);
+        compute(kt & 1);
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    const float alpha = p.alpha;
+    const float* bias = p.bias;
+    if (bias && p.step_ptr) bias += (long long)(*p.step_ptr) * p.bias_step_stride;
+    uint16_t* __restrict__ C = p.C + bz * p.sC;
+    const uint16_t* __restrict__ R = p.R ? p.R + bz * p.sR : nullptr;
+
+    if (p.epi == 1) {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows of the same channels
+        if constexpr (TN % 2 == 0) {
+            const int nout = p.N >> 1;
+#pragma unroll
+            for (int nt = 0; nt < TN; nt += 2)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    const int m = m0 + wm * TM * 32 + mt * 32 + l31;
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int nv = n0 + wn * TN * 32 + nt * 32 + 8 * g4 + 4 * lhi;  // value row (permuted index)
+                        const int oc = ((n0 + wn * TN * 32 + nt * 32) >> 1) + 8 * g4 + 4 * lhi;
+                        if (oc >= nout) continue;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float a = acc[nt][mt][4 * g4 + e] * alpha;
+                            float g = acc[nt + 1][mt][4 * g4 + e] * alpha;
+                            if (bias) {
+                                a += bias[nv + e];
+                                g += bias[nv + 32 + e];
+                            }
+                            v[e] = a * gelu_erf_f(g);
+                        }
+                        uint2 o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2*)(C + (long long)m * p.ldc + oc) = o;
+                    }
+                }
+        }
+        return;
+    }
+
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m0 + wm * TM * 32 + mt * 32 + l31;
+            if (m >= p.M) continue;
+            const float bm_ = (bias && p.bias_mode == 2) ? bias[m] : 0.f;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nb = n0 + wn * TN * 32 + nt * 32 + 8 * g4 + 4 * lhi;
+                if (nb >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[nt][mt][4 * g4 + e] * alpha + bm_;
+                    if (bias && p.bias_mode == 1 && nb + e < p.N) v[e] += bias[nb + e];
+                }
+                if (vec_ok && nb + 3 < p.N) {
+                    if (R) {
+                        const uint2 r = *(const uint2*)(R + (long long)m * p.ldr + nb);
+                        v[0] += __uint_as_float(r.x << 16);
+                        v[1] += __uint_as_float(r.x & 0xffff0000u);
+                        v[2] += __uint_as_float(r.y << 16);
+                        v[3] += __uint_as_float(r.y & 0xffff0000u);
+                    }
+                    if (p.epi == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)(C + (long long)m * p.ldc + nb) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (nb + e >= p.N) continue;
+                        float t = v[e];
+                        if (R) t += bf16_to_f32(R[(long long)m * p.ldr + nb + e]);
+                        if (p.epi == 2) t = silu_f(t);
+                        C[(long long)m * p.ldc + nb + e] = f32_to_bf16(t);
+                    }
+                }
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (LDS > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(256), LDS, stream, a);
+    SDV_CHECK_LAUNCH("sdv_gemm_bf16");
+    return SDV_OK;
+}
+
+}  // namespace
+
+extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
+    SDV_REQUIRE(args != nullptr, "sdv_gemm_bf16: null args");
+    sdv_gemm_args a = *args;
+    SDV_REQUIRE(a.X && a.W && a.C, "sdv_gemm_bf16: null operand");
+    SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    SDV_REQUIRE(a.K % kBK == 0, "sdv_gemm_bf16: K=%d must be a multiple of %d", a.K, kBK);
+    SDV_REQUIRE(a.mode >= 0 && a.mode <= 3, "sdv_gemm_bf16: bad mode %d", a.mode);
+    if (!a.X2) {
+        a.C1 = a.K;
+        a.ldx2 = a.ldx;
+        a.X2 = a.X;
+    }
+    SDV_REQUIRE(a.C1 % kBK == 0 && a.C1 > 0 && a.C1 <= a.K, "sdv_gemm_bf16: C1=%d must be a multiple of %d in (0,K]",
+                a.C1, kBK);
+    SDV_REQUIRE(a.ldx % 8 == 0 && a.ldx2 % 8 == 0 && a.ldw % 8 == 0, "sdv_gemm_bf16: ldx/ldx2/ldw must be multiples of 8");
+    if (a.mode != 0) {
+        SDV_REQUIRE(a.zero_page != nullptr, "sdv_gemm_bf16: conv modes need zero_page");
+        SDV_REQUIRE(a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "sdv_gemm_bf16: bad conv geometry");
+        SDV_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "sdv_gemm_bf16: M must be nimg*Hout*Wout");
+        SDV_REQUIRE(a.ldw >= 9 * a.K, "sdv_gemm_bf16: conv weights must be [N][3][3][K]");
+        SDV_REQUIRE(a.batch <= 1, "sdv_gemm_bf16: conv modes are not batched");
+        if (a.mode == 1) SDV_REQUIRE(a.Hin == a.Hout && a.Win == a.Wout, "conv s1 geometry");
+        if (a.mode == 2) SDV_REQUIRE(a.Hout == (a.Hin + 1) / 2 && a.Wout == (a.Win + 1) / 2, "conv s2 geometry");
+        if (a.mode == 3) SDV_REQUIRE(a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win, "upsample-conv geometry");
+    }
+    if (a.epi == 1) {
+        SDV_REQUIRE(a.N % 64 == 0, "sdv_gemm_bf16: GEGLU needs N %% 64 == 0");
+        SDV_REQUIRE(a.ldc % 4 == 0, "sdv_gemm_bf16: GEGLU needs ldc %% 4 == 0");
+    }
+    if (a.bias_mode == 0 && a.bias) a.bias_mode = 1;
+    if (a.alpha == 0.f) a.alpha = 1.f;
+    hipStream_t s = (hipStream_t)stream;
+    int tile = a.tile;
+    if (tile == 0) {
+        // enough 128x128 tiles to cover the chip twice -> big tile; N not a multiple of 128 but of 64
+        // (e.g. 320 channels) -> 128x64 to avoid padded MFMA work; otherwise small tiles for occupancy.
+        const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
+        if (a.N % 128 != 0 && a.N % 64 == 0 && a.N <= 320)
+            tile = 2;
+        else if (big >= 256 || a.epi == 1)
+            tile = 1;
+        else {
+            const long long mid = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * (a.batch > 0 ? a.batch : 1);
+            tile = mid >= 256 ? 2 : 3;
+        }
+    }
+    if (a.epi == 1 && tile == 3) tile = 2;
+    switch (tile) {
+        case 1: return launch_igemm<2, 2, 2, 2>(a, s);
+        case 2: return launch_igemm<4, 1, 1, 2>(a, s);
+        case 3: return launch_igemm<2, 2, 1, 1>(a, s);
+        case 4: return launch_igemm<2, 2, 4, 2>(a, s);
+        default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
+    }
+    return SDV_OK;
+}

@@ -1,0 +1,250 @@
+// GroupNorm (+SiLU, + skip-connection concat) and LayerNorm over NHWC / token-major bf16 activations.
+// Replaces nn.GroupNorm / F.silu / torch.cat / nn.LayerNorm inside unet(...) and vae.decode(...)
+// (/root/reference/.../stable_diffusion_pipeline.py:418, :433).  HBM-bound: every access is a 16-byte
+// (8 x bf16) vector, each thread keeps ONE channel chunk so the affine parameters live in registers,
+// statistics accumulate in fp32.
+#include "sdv_common.h"
+
+namespace {
+
+// Thread layout shared by stats/apply: a block walks `npix` pixels of one image; thread t owns channel
+// chunk (t % CT) [8 channels] and pixel lane (t / CT); chunks beyond 256 are looped.
+struct GnGeom {
+    int C, nchunk, CT, PT;
+};
+__device__ __forceinline__ GnGeom gn_geom(int C) {
+    GnGeom g;
+    g.C = C;
+    g.nchunk = C >> 3;
+    g.CT = g.nchunk < 256 ? g.nchunk : 256;
+    g.PT = 256 / g.CT;
+    return g;
+}
+
+__device__ __forceinline__ const uint16_t* gn_src(const uint16_t* X, const uint16_t* X2, int C1, int C2, long long pix,
+                                                  int c0) {
+    return c0 < C1 ? X + pix * C1 + c0 : X2 + pix * C2 + (c0 - C1);
+}
+
+// partials[img][split][group][2] = (sum, sumsq) over this block's pixel range.
+// Deterministic: every thread parks its per-channel partial sums in LDS ([pixel-lane][channel][2]) and one
+// thread per group folds them in a fixed order - no atomics, so frames are bit-reproducible run to run.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ X2,
+                                                       int C1, int C2, int HW, int groups, int splits,
+                                                       float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [PT][C][2]
+    const int C = C1 + C2;
+    const GnGeom g = gn_geom(C);
+    const int cpg = C / groups;
+    const int img = blockIdx.y, split = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int per = (HW + splits - 1) / splits;
+    const int p_begin = split * per;
+    const int p_end = p_begin + per < HW ? p_begin + per : HW;
+    const int tc = tid % g.CT, tp = tid / g.CT;
+    if (tp < g.PT) {
+        for (int ch = tc; ch < g.nchunk; ch += g.CT) {
+            const int c0 = ch << 3;
+            float s[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+            for (int p = p_begin + tp; p < p_end; p += g.PT) {
+                const long long pix = (long long)img * HW + p;
+                const bf16x8_raw r = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, pix, c0);
+                float f[8];
+                unpack8(r, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s[e] += f[e];
+                    q[e] += f[e] * f[e];
+                }
+            }
+            float* dst = sm + ((long long)tp * C + c0) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                dst[2 * e] = s[e];
+                dst[2 * e + 1] = q[e];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float as = 0.f, aq = 0.f;
+        for (int t = 0; t < g.PT; ++t) {
+            const float* src = sm + ((long long)t * C + tid * cpg) * 2;
+            for (int c = 0; c < cpg; ++c) {
+                as += src[2 * c];
+                aq += src[2 * c + 1];
+            }
+        }
+        float* out = partials + (((long long)img * splits + split) * groups + tid) * 2;
+        out[0] = as;
+        out[1] = aq;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ X2,
+                                                       int C1, int C2, int HW, int groups, int splits,
+                                                       const float* __restrict__ partials,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int silu, int pix_per_block,
+                                                       uint16_t* __restrict__ Y) {
+    __shared__ float gmean[64], grstd[64];
+    const int C = C1 + C2;
+    const GnGeom g = gn_geom(C);
+    const int cpg = C / groups;
+    const int img = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < groups) {
+        float s = 0.f, q = 0.f;
+        for (int sp = 0; sp < splits; ++sp) {
+            const float* in = partials + (((long long)img * splits + sp) * groups + tid) * 2;
+            s += in[0];
+            q += in[1];
+        }
+        const float cnt = (float)HW * (float)cpg;
+        const float mean = s / cnt;
+        float var = q / cnt - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        gmean[tid] = mean;
+        grstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int p_begin = blockIdx.x * pix_per_block;
+    const int p_end = p_begin + pix_per_block < HW ? p_begin + pix_per_block : HW;
+    const int tc = tid % g.CT, tp = tid / g.CT;
+    if (tp >= g.PT) return;
+    for (int ch = tc; ch < g.nchunk; ch += g.CT) {
+        const int c0 = ch << 3;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            const int ge = c / cpg;
+            const float a = grstd[ge] * gamma[c];
+            sc[e] = a;
+            sh[e] = beta[c] - gmean[ge] * a;
+        }
+        for (int p = p_begin + tp; p < p_end; p += g.PT) {
+            const long long pix = (long long)img * HW + p;
+            const bf16x8_raw r = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, pix, c0);
+            float f[8];
+            unpack8(r, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = f[e] * sc[e] + sh[e];
+                f[e] = silu ? silu_f(v) : v;
+            }
+            *(bf16x8_raw*)(Y + pix * C + c0) = pack8(f);
+        }
+    }
+}
+
+// one wave per row; C <= 8 * 64 * MAXC chunks
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, long long rows, int C,
+                                                        uint16_t* __restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C >> 3;
+    const uint16_t* x = X + row * C;
+    float f[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            const bf16x8_raw r = *(const bf16x8_raw*)(x + ch * 8);
+            unpack8(r, f[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = f[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    uint16_t* y = Y + row * C;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = ch * 8 + e;
+                o[e] = (f[i][e] - mean) * rstd * gamma[c] + beta[c];
+            }
+            *(bf16x8_raw*)(y + ch * 8) = pack8(o);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sdv_groupnorm_stats(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
+                                   int32_t HW, int32_t groups, int32_t splits, float* partials, void* stream) {
+    SDV_REQUIRE(X && partials, "sdv_groupnorm_stats: null pointer");
+    SDV_REQUIRE(C2 == 0 || X2, "sdv_groupnorm_stats: C2 > 0 needs X2");
+    const int C = C1 + C2;
+    SDV_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C > 0, "sdv_groupnorm_stats: channels must be multiples of 8");
+    SDV_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "sdv_groupnorm_stats: bad groups %d for C=%d", groups, C);
+    SDV_REQUIRE(splits > 0 && nimg > 0 && HW > 0, "sdv_groupnorm_stats: bad sizes");
+    const int nchunk = C / 8;
+    const int CT = nchunk < 256 ? nchunk : 256;
+    const size_t lds = (size_t)(256 / CT) * C * 2 * sizeof(float);
+    SDV_REQUIRE(lds <= 64 * 1024, "sdv_groupnorm_stats: C=%d too large", C);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, nimg), dim3(256), lds, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,
+                       groups, splits, partials);
+    SDV_CHECK_LAUNCH("sdv_groupnorm_stats");
+    return SDV_OK;
+}
+
+extern "C" int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
+                                   int32_t HW, int32_t groups, int32_t splits, const float* partials,
+                                   const float* gamma, const float* beta, float eps, int32_t silu, sdv_bf16* Y,
+                                   void* stream) {
+    SDV_REQUIRE(X && partials && gamma && beta && Y, "sdv_groupnorm_apply: null pointer");
+    SDV_REQUIRE(C2 == 0 || X2, "sdv_groupnorm_apply: C2 > 0 needs X2");
+    const int C = C1 + C2;
+    SDV_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C > 0, "sdv_groupnorm_apply: channels must be multiples of 8");
+    SDV_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "sdv_groupnorm_apply: bad groups");
+    // ~32 KB of activation per block keeps > 2k blocks in flight on the big tensors
+    int ppb = (16384 + C - 1) / C;
+    if (ppb < 1) ppb = 1;
+    const int nblk = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nimg), dim3(256), 0, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,
+                       groups, splits, partials, gamma, beta, eps, silu, ppb, Y);
+    SDV_CHECK_LAUNCH("sdv_groupnorm_apply");
+    return SDV_OK;
+}
+
+extern "C" int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta, float eps, int64_t rows,
+                                  int32_t C, sdv_bf16* Y, void* stream) {
+    SDV_REQUIRE(X && gamma && beta && Y, "sdv_layernorm_bf16: null pointer");
+    SDV_REQUIRE(C % 8 == 0 && C > 0 && C <= 8 * 64 * 4, "sdv_layernorm_bf16: C=%d unsupported (multiple of 8, <= 2048)", C);
+    SDV_REQUIRE(rows > 0, "sdv_layernorm_bf16: rows");
+    dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = C / 8;
+    if (nchunk <= 64)
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, C, Y);
+    else if (nchunk <= 128)
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, C, Y);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, C, Y);
+    SDV_CHECK_LAUNCH("sdv_layernorm_bf16");
+    return SDV_OK;
+}

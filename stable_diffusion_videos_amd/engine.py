@@ -1,0 +1,369 @@
+"""MI355X-native executors for the two networks on the walk hot path.
+
+``UNetEngine.forward``      replaces ``self.unet(x, t, encoder_hidden_states=ctx).sample``
+                            (/root/reference/stable_diffusion_videos/stable_diffusion_pipeline.py:418)
+``VAEDecoderEngine.decode`` replaces ``self.vae.decode(latents).sample`` + the image epilogue
+                            (stable_diffusion_pipeline.py:432-438, numpy_to_pil :450)
+
+Everything is NHWC / token-major bf16 in HBM ([N*H*W, C] row-major), so the UNet's conv <-> transformer
+boundaries need no permutes.  Each method only enqueues HIP kernels (through ``hip``, the ctypes binding of
+libsdv_hip.so) on the current stream: a whole denoise step is therefore capturable in one hipGraph.
+
+What is hoisted out of the 50-step loop (the reference recomputes all of it every step):
+  * the timestep-embedding MLP and the 22 ``time_emb_proj`` projections: the walk uses the same timestep
+    for every sample, so they collapse to a [steps, Cout] bias table per ResBlock, folded into conv1's bias
+    and indexed on-device by a step counter (graph replay needs no new arguments);
+  * the cross-attention K / V projections of the text context (constant over all steps).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import hip
+from .config import UNetConfig, VAEConfig
+from .weights import StateDict, conv_w, geglu_interleave, lin_w, vec
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+# shared blocks
+# ------------------------------------------------------------------------------------------------
+class _Res:
+    """ResnetBlock2D: GN+SiLU -> conv3x3 (+temb bias) -> GN+SiLU -> conv3x3 (+ shortcut/residual)."""
+
+    def __init__(self, sd: StateDict, p: str, device, groups: int, eps: float, has_temb: bool):
+        self.g1, self.b1 = vec(sd[p + ".norm1.weight"], device), vec(sd[p + ".norm1.bias"], device)
+        self.w1 = conv_w(sd[p + ".conv1.weight"], device)
+        self.c1_bias = vec(sd[p + ".conv1.bias"], device)
+        self.g2, self.b2 = vec(sd[p + ".norm2.weight"], device), vec(sd[p + ".norm2.bias"], device)
+        self.w2 = conv_w(sd[p + ".conv2.weight"], device)
+        self.c2_bias = vec(sd[p + ".conv2.bias"], device)
+        self.cout = self.w1.shape[0]
+        self.groups, self.eps = groups, eps
+        if has_temb:
+            self.wt = lin_w(sd[p + ".time_emb_proj.weight"], device)
+            self.bt = vec(sd[p + ".time_emb_proj.bias"], device)
+        else:
+            self.wt = None
+        if p + ".conv_shortcut.weight" in sd:
+            self.ws = lin_w(sd[p + ".conv_shortcut.weight"], device)
+            self.bs = vec(sd[p + ".conv_shortcut.bias"], device)
+        else:
+            self.ws = None
+        self.bias_table: Optional[torch.Tensor] = None  # [steps, Cout] = conv1.bias + time_emb_proj(silu(emb_t))
+
+    def prepare_timesteps(self, emb: torch.Tensor):
+        self.bias_table = hip.linear_small(emb, self.wt, self.bt, add=self.c1_bias, silu_in=True)
+
+    def __call__(self, x, x2, nimg, H, W, step_ptr, circular):
+        HW = H * W
+        h = hip.groupnorm(x, self.g1, self.b1, nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True, x2=x2)
+        if self.wt is not None:
+            h = hip.conv3x3(h, self.w1, self.bias_table, nimg=nimg, H=H, W=W, circular=circular, step_ptr=step_ptr,
+                            bias_step_stride=self.cout)
+        else:
+            h = hip.conv3x3(h, self.w1, self.c1_bias, nimg=nimg, H=H, W=W, circular=circular)
+        h = hip.groupnorm(h, self.g2, self.b2, nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True)
+        if self.ws is not None:
+            sc = hip.linear(x, self.ws, self.bs, x2=x2)
+        else:
+            assert x2 is None
+            sc = x
+        return hip.conv3x3(h, self.w2, self.c2_bias, nimg=nimg, H=H, W=W, residual=sc, circular=circular)
+
+
+class _Transformer:
+    """Transformer2DModel with one BasicTransformerBlock (self-attn, text cross-attn, GEGLU FF)."""
+
+    def __init__(self, sd: StateDict, p: str, device, heads: int, groups: int):
+        self.gn_g, self.gn_b = vec(sd[p + ".norm.weight"], device), vec(sd[p + ".norm.bias"], device)
+        self.w_in, self.b_in = lin_w(sd[p + ".proj_in.weight"], device), vec(sd[p + ".proj_in.bias"], device)
+        self.w_out, self.b_out = lin_w(sd[p + ".proj_out.weight"], device), vec(sd[p + ".proj_out.bias"], device)
+        b = p + ".transformer_blocks.0"
+        self.ln = [(vec(sd[f"{b}.norm{i}.weight"], device), vec(sd[f"{b}.norm{i}.bias"], device)) for i in (1, 2, 3)]
+        self.wqk1 = lin_w(torch.cat([sd[f"{b}.attn1.to_q.weight"], sd[f"{b}.attn1.to_k.weight"]], 0), device)
+        self.wv1 = lin_w(sd[f"{b}.attn1.to_v.weight"], device)
+        self.wo1, self.bo1 = lin_w(sd[f"{b}.attn1.to_out.0.weight"], device), vec(sd[f"{b}.attn1.to_out.0.bias"], device)
+        self.wq2 = lin_w(sd[f"{b}.attn2.to_q.weight"], device)
+        self.wk2 = lin_w(sd[f"{b}.attn2.to_k.weight"], device)
+        self.wv2 = lin_w(sd[f"{b}.attn2.to_v.weight"], device)
+        self.wo2, self.bo2 = lin_w(sd[f"{b}.attn2.to_out.0.weight"], device), vec(sd[f"{b}.attn2.to_out.0.bias"], device)
+        self.wff1 = lin_w(geglu_interleave(sd[f"{b}.ff.net.0.proj.weight"]), device)
+        self.bff1 = vec(geglu_interleave(sd[f"{b}.ff.net.0.proj.bias"]), device)
+        self.wff2, self.bff2 = lin_w(sd[f"{b}.ff.net.2.weight"], device), vec(sd[f"{b}.ff.net.2.bias"], device)
+        self.C = self.w_in.shape[0]
+        self.heads = heads
+        self.dh = self.C // heads
+        self.groups = groups
+        # per batch size: (K [N*Lc, C], V^T [N, C, ldv] zero padded, Lc) - persistent so captured graphs stay valid
+        self.ctx: Dict[int, tuple] = {}
+
+    def prepare_context(self, ctx: torch.Tensor, nimg: int, Lc: int):
+        """ctx: bf16 [nimg*Lc, D].  K = ctx Wk^T ; V^T[n] = Wv ctx[n]^T  (constant across denoise steps)."""
+        C, D = self.C, ctx.shape[1]
+        ldv = _round_up(Lc, 64)
+        ent = self.ctx.get(nimg)
+        if ent is None or ent[2] != Lc:
+            ent = (torch.empty((nimg * Lc, C), dtype=BF16, device=ctx.device),
+                   torch.zeros((nimg, C, ldv), dtype=BF16, device=ctx.device), Lc)
+            self.ctx[nimg] = ent
+        hip.linear(ctx, self.wk2, out=ent[0])
+        hip.gemm(self.wv2, ctx, ent[1], M=C, N=Lc, K=D, ldx=D, ldw=D, ldc=ldv, batch=nimg, sX=0, sW=Lc * D,
+                 sC=C * ldv)
+
+    def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor):
+        C, HW, heads, dh = self.C, H * W, self.heads, self.dh
+        M = nimg * HW
+        scale = dh ** -0.5
+        h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nimg, HW=HW, groups=self.groups, eps=1e-6, silu=False)
+        h = hip.linear(h, self.w_in, self.b_in)
+        # --- self attention ---
+        n1 = hip.layernorm(h, *self.ln[0])
+        qk = hip.linear(n1, self.wqk1)                                    # [M, 2C] = [Q | K]
+        ldv = _round_up(HW, 64)
+        hip.gemm(self.wv1, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nimg, sX=0, sW=HW * C,
+                 sC=C * ldv)                                              # V^T [nimg][C][ldv]
+        o = torch.empty((M, C), dtype=BF16, device=x.device)
+        hip.attention(qk, qk, vt_ws, o, B=nimg, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
+                      scale=scale, k_off=C)
+        h = hip.linear(o, self.wo1, self.bo1, residual=h)
+        # --- cross attention on the text context ---
+        n2 = hip.layernorm(h, *self.ln[1])
+        q = hip.linear(n2, self.wq2)
+        o2 = torch.empty((M, C), dtype=BF16, device=x.device)
+        ctx_k, ctx_vt, Lc = self.ctx[nimg]
+        hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
+                      ldo=C, scale=scale)
+        h = hip.linear(o2, self.wo2, self.bo2, residual=h)
+        # --- GEGLU feed-forward ---
+        n3 = hip.layernorm(h, *self.ln[2])
+        g = hip.linear(n3, self.wff1, self.bff1, epi=1)                   # [M, 4C]
+        h = hip.linear(g, self.wff2, self.bff2, residual=h)
+        return hip.linear(h, self.w_out, self.b_out, residual=x)
+
+
+# ------------------------------------------------------------------------------------------------
+# UNet
+# ------------------------------------------------------------------------------------------------
+class UNetEngine:
+    def __init__(self, cfg: UNetConfig, sd: StateDict, device, tiled: bool = False):
+        hip.load()
+        self.cfg, self.device, self.tiled = cfg, torch.device(device), tiled
+        self.config = cfg                      # ``pipe.unet.config.sample_size`` (reference :268)
+        self.in_channels = cfg.in_channels     # ``pipe.unet.in_channels`` (reference :367)
+        ch = cfg.block_out_channels
+        g, eps = cfg.norm_num_groups, cfg.norm_eps
+        dev = self.device
+        self.conv_in_w = conv_w(sd["conv_in.weight"], dev)
+        self.conv_in_b = vec(sd["conv_in.bias"], dev)
+        self.t_w1, self.t_b1 = lin_w(sd["time_embedding.linear_1.weight"], dev), vec(sd["time_embedding.linear_1.bias"], dev)
+        self.t_w2, self.t_b2 = lin_w(sd["time_embedding.linear_2.weight"], dev), vec(sd["time_embedding.linear_2.bias"], dev)
+        self.res: List[_Res] = []
+        self.tfm: List[_Transformer] = []
+
+        def res(p):
+            r = _Res(sd, p, dev, g, eps, True)
+            self.res.append(r)
+            return r
+
+        def tfm(p, level):
+            t = _Transformer(sd, p, dev, cfg.heads(level), g)
+            self.tfm.append(t)
+            return t
+
+        self.down = []
+        for i, typ in enumerate(cfg.down_block_types):
+            blk = {"res": [], "attn": [], "down": None}
+            for j in range(cfg.layers_per_block):
+                blk["res"].append(res(f"down_blocks.{i}.resnets.{j}"))
+                if typ.startswith("CrossAttn"):
+                    blk["attn"].append(tfm(f"down_blocks.{i}.attentions.{j}", i))
+            if i != len(ch) - 1:
+                blk["down"] = (conv_w(sd[f"down_blocks.{i}.downsamplers.0.conv.weight"], dev),
+                               vec(sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], dev))
+            self.down.append(blk)
+        self.mid = (res("mid_block.resnets.0"), tfm("mid_block.attentions.0", len(ch) - 1), res("mid_block.resnets.1"))
+        self.up = []
+        for i, typ in enumerate(cfg.up_block_types):
+            blk = {"res": [], "attn": [], "up": None}
+            for j in range(cfg.layers_per_block + 1):
+                blk["res"].append(res(f"up_blocks.{i}.resnets.{j}"))
+                if typ.startswith("CrossAttn"):
+                    blk["attn"].append(tfm(f"up_blocks.{i}.attentions.{j}", len(ch) - 1 - i))
+            if i != len(ch) - 1:
+                blk["up"] = (conv_w(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"], dev),
+                             vec(sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], dev))
+            self.up.append(blk)
+        self.out_g, self.out_b = vec(sd["conv_norm_out.weight"], dev), vec(sd["conv_norm_out.bias"], dev)
+        self.conv_out_w = conv_w(sd["conv_out.weight"], dev)
+        self.conv_out_b = vec(sd["conv_out.bias"], dev)
+        self.groups, self.eps = g, eps
+        self._vt_ws: Dict[tuple, torch.Tensor] = {}
+        self.num_steps = 0
+
+    # -- per-walk preparation ----------------------------------------------------------------
+    def prepare_timesteps(self, timesteps: Sequence[int]):
+        """Build the per-ResBlock [steps, Cout] bias tables for this timestep schedule."""
+        cfg = self.cfg
+        ts = torch.tensor([float(t) for t in timesteps], dtype=F32, device=self.device)
+        t_emb = hip.timestep_embedding(ts, cfg.block_out_channels[0], cfg.flip_sin_to_cos, float(cfg.freq_shift))
+        e = hip.linear_small(t_emb, self.t_w1, self.t_b1)
+        emb = hip.linear_small(e, self.t_w2, self.t_b2, silu_in=True)     # [steps, temb]
+        for r in self.res:
+            r.prepare_timesteps(emb)
+        self.num_steps = len(timesteps)
+
+    def prepare_context(self, ctx: torch.Tensor):
+        """ctx: [nimg, Lc, D] (any float dtype) -> cache cross-attention K / V^T in every transformer block."""
+        nimg, Lc, D = ctx.shape
+        c = ctx.reshape(nimg * Lc, D)
+        c = hip.f32_to_bf16(c.float()) if c.dtype != BF16 else c.contiguous()
+        for t in self.tfm:
+            t.prepare_context(c, nimg, Lc)
+
+    def _vt(self, nimg: int, C: int, HW: int) -> torch.Tensor:
+        """Zero-initialised V^T workspace, shared by all blocks of one (C, HW) shape (stream-ordered)."""
+        key = (nimg, C, HW)
+        if key not in self._vt_ws:
+            self._vt_ws[key] = torch.zeros((nimg, C, _round_up(HW, 64)), dtype=BF16, device=self.device)
+        return self._vt_ws[key]
+
+    def reserve(self, nimg: int, H: int, W: int):
+        """Allocate the persistent workspaces outside of graph capture."""
+        h, w = H, W
+        for i, blk in enumerate(self.down):
+            for t in blk["attn"]:
+                self._vt(nimg, t.C, h * w)
+            if blk["down"] is not None:
+                h, w = (h + 1) // 2, (w + 1) // 2
+        self._vt(nimg, self.mid[1].C, h * w)
+        for blk in self.up:
+            for t in blk["attn"]:
+                self._vt(nimg, t.C, h * w)
+            if blk["up"] is not None:
+                h, w = 2 * h, 2 * w
+
+    # -- one denoise forward -----------------------------------------------------------------
+    def forward(self, x: torch.Tensor, nimg: int, H: int, W: int, step_ptr: torch.Tensor) -> torch.Tensor:
+        """x: bf16 NHWC [nimg*H*W, Cin]; returns eps fp32 NHWC [nimg, H, W, Cout].  The timestep is
+        the ``*step_ptr``-th entry of the schedule given to ``prepare_timesteps``."""
+        circ = self.tiled
+        h = hip.conv3x3_cin_small(x, self.conv_in_w, self.conv_in_b, nimg=nimg, H=H, W=W, circular=circ)
+        skips = [h]
+        hh, ww = H, W
+        for blk in self.down:
+            for j, r in enumerate(blk["res"]):
+                h = r(h, None, nimg, hh, ww, step_ptr, circ)
+                if blk["attn"]:
+                    t = blk["attn"][j]
+                    h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww))
+                skips.append(h)
+            if blk["down"] is not None:
+                wd, bd = blk["down"]
+                h = hip.conv3x3(h, wd, bd, nimg=nimg, H=hh, W=ww, mode=2, circular=circ)
+                hh, ww = (hh + 1) // 2, (ww + 1) // 2
+                skips.append(h)
+        r0, t0, r1 = self.mid
+        h = r0(h, None, nimg, hh, ww, step_ptr, circ)
+        h = t0(h, nimg, hh, ww, self._vt(nimg, t0.C, hh * ww))
+        h = r1(h, None, nimg, hh, ww, step_ptr, circ)
+        for blk in self.up:
+            for j, r in enumerate(blk["res"]):
+                h = r(h, skips.pop(), nimg, hh, ww, step_ptr, circ)
+                if blk["attn"]:
+                    t = blk["attn"][j]
+                    h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww))
+            if blk["up"] is not None:
+                wu, bu = blk["up"]
+                h = hip.conv3x3(h, wu, bu, nimg=nimg, H=hh, W=ww, mode=3, circular=circ)
+                hh, ww = 2 * hh, 2 * ww
+        h = hip.groupnorm(h, self.out_g, self.out_b, nimg=nimg, HW=hh * ww, groups=self.groups, eps=self.eps, silu=True)
+        eps = torch.empty((nimg, hh, ww, self.cfg.out_channels), dtype=F32, device=self.device)
+        hip.conv3x3_cout_small(h, self.conv_out_w, self.conv_out_b, nimg=nimg, H=hh, W=ww, out_mode=0, out_f32=eps,
+                               circular=circ)
+        return eps
+
+
+# ------------------------------------------------------------------------------------------------
+# VAE decoder
+# ------------------------------------------------------------------------------------------------
+class VAEDecoderEngine:
+    def __init__(self, cfg: VAEConfig, sd: StateDict, device, tiled: bool = False):
+        hip.load()
+        self.cfg, self.device, self.tiled = cfg, torch.device(device), tiled
+        self.config = cfg
+        dev = self.device
+        g = cfg.norm_num_groups
+        ch = list(reversed(cfg.block_out_channels))
+        lc = cfg.latent_channels
+        self.pq_w = sd["post_quant_conv.weight"].reshape(lc, lc).contiguous().to(dev, F32)
+        self.pq_b = vec(sd["post_quant_conv.bias"], dev)
+        self.conv_in_w, self.conv_in_b = conv_w(sd["decoder.conv_in.weight"], dev), vec(sd["decoder.conv_in.bias"], dev)
+        self.mid_res = [_Res(sd, f"decoder.mid_block.resnets.{i}", dev, g, 1e-6, False) for i in range(2)]
+        a = "decoder.mid_block.attentions.0"
+        self.a_g, self.a_b = vec(sd[a + ".group_norm.weight"], dev), vec(sd[a + ".group_norm.bias"], dev)
+        self.a_wqk = lin_w(torch.cat([sd[a + ".to_q.weight"], sd[a + ".to_k.weight"]], 0), dev)
+        self.a_bqk = vec(torch.cat([sd[a + ".to_q.bias"], sd[a + ".to_k.bias"]], 0), dev)
+        self.a_wv, self.a_bv = lin_w(sd[a + ".to_v.weight"], dev), vec(sd[a + ".to_v.bias"], dev)
+        self.a_wo, self.a_bo = lin_w(sd[a + ".to_out.0.weight"], dev), vec(sd[a + ".to_out.0.bias"], dev)
+        self.up = []
+        for i in range(len(ch)):
+            blk = {"res": [_Res(sd, f"decoder.up_blocks.{i}.resnets.{j}", dev, g, 1e-6, False)
+                           for j in range(cfg.layers_per_block + 1)], "up": None}
+            if i != len(ch) - 1:
+                blk["up"] = (conv_w(sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"], dev),
+                             vec(sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"], dev))
+            self.up.append(blk)
+        self.out_g, self.out_b = vec(sd["decoder.conv_norm_out.weight"], dev), vec(sd["decoder.conv_norm_out.bias"], dev)
+        self.conv_out_w, self.conv_out_b = conv_w(sd["decoder.conv_out.weight"], dev), vec(sd["decoder.conv_out.bias"], dev)
+        self.groups = g
+        self.scale_factor = 2 ** (len(cfg.block_out_channels) - 1)
+
+    def _attention(self, x, nimg, H, W):
+        C, HW = x.shape[1], H * W
+        n = hip.groupnorm(x, self.a_g, self.a_b, nimg=nimg, HW=HW, groups=self.groups, eps=1e-6, silu=False)
+        qk = hip.linear(n, self.a_wqk, self.a_bqk)                                   # [M, 2C]
+        vt = torch.empty((nimg, C, HW), dtype=BF16, device=x.device)
+        hip.gemm(self.a_wv, n, vt, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=HW, bias=self.a_bv, bias_mode=2, batch=nimg,
+                 sX=0, sW=HW * C, sC=C * HW)                                         # V^T (+ bias per channel)
+        s = torch.empty((nimg, HW, HW), dtype=BF16, device=x.device)
+        hip.gemm(qk, qk, s, M=HW, N=HW, K=C, ldx=2 * C, ldw=2 * C, ldc=HW, alpha=C ** -0.5, batch=nimg,
+                 sX=HW * 2 * C, sW=HW * 2 * C, sC=HW * HW, w_off=C)                  # S = Q K^T / sqrt(C)
+        hip.softmax_rows_(s, nimg * HW, HW, HW)
+        o = torch.empty((nimg * HW, C), dtype=BF16, device=x.device)
+        hip.gemm(s, vt, o, M=HW, N=C, K=HW, ldx=HW, ldw=HW, ldc=C, batch=nimg, sX=HW * HW, sW=C * HW, sC=HW * C)
+        return hip.linear(o, self.a_wo, self.a_bo, residual=x)
+
+    def decode(self, latents: torch.Tensor, want_float: bool = False):
+        """latents: fp32 NHWC [B, h, w, 4] (UNSCALED, as they leave the denoise loop).  Returns
+        (uint8 NHWC images [B, 8h, 8w, 3], optional fp32 NHWC images in [0,1])."""
+        B, h, w, lc = latents.shape
+        circ = self.tiled
+        z = torch.empty((B * h * w, lc), dtype=BF16, device=self.device)
+        hip.latent_affine(latents.contiguous(), self.pq_w, self.pq_b, 1.0 / self.cfg.scaling_factor, z, B * h * w, lc)
+        x = hip.conv3x3_cin_small(z, self.conv_in_w, self.conv_in_b, nimg=B, H=h, W=w, circular=circ)
+        x = self.mid_res[0](x, None, B, h, w, None, circ)
+        x = self._attention(x, B, h, w)
+        x = self.mid_res[1](x, None, B, h, w, None, circ)
+        for blk in self.up:
+            for r in blk["res"]:
+                x = r(x, None, B, h, w, None, circ)
+            if blk["up"] is not None:
+                wu, bu = blk["up"]
+                x = hip.conv3x3(x, wu, bu, nimg=B, H=h, W=w, mode=3, circular=circ)
+                h, w = 2 * h, 2 * w
+        x = hip.groupnorm(x, self.out_g, self.out_b, nimg=B, HW=h * w, groups=self.groups, eps=1e-6, silu=True)
+        oc = self.cfg.out_channels
+        u8 = torch.empty((B, h, w, oc), dtype=torch.uint8, device=self.device)
+        f32 = torch.empty((B, h, w, oc), dtype=F32, device=self.device) if want_float else None
+        hip.conv3x3_cout_small(x, self.conv_out_w, self.conv_out_b, nimg=B, H=h, W=w, out_mode=1, out_f32=f32,
+                               out_u8=u8, circular=circ)
+        return u8, f32

@@ -1,0 +1,363 @@
+"""ctypes binding of libsdv_hip.so (C ABI: include/sdv_hip.h).
+
+PyTorch is used for device memory and streams only: every wrapper takes torch tensors, checks
+dtype/device/contiguity, and passes ``data_ptr()`` + the current HIP stream to the C entry point.
+There is NO fallback: if the library is missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsdv_hip.so"
+_lib = None
+
+
+class SdvHipError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("X2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+        ("C", C.c_void_p), ("step_ptr", C.c_void_p), ("zero_page", C.c_void_p),
+        ("sX", C.c_int64), ("sW", C.c_int64), ("sC", C.c_int64), ("sR", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("ldx", C.c_int32), ("ldx2", C.c_int32), ("C1", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32),
+        ("ldr", C.c_int32),
+        ("mode", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("circular", C.c_int32),
+        ("epi", C.c_int32), ("bias_mode", C.c_int32), ("bias_step_stride", C.c_int32),
+        ("batch", C.c_int32), ("tile", C.c_int32), ("alpha", C.c_float),
+    ]
+
+
+_SIGNATURES = {
+    "sdv_last_error": (C.c_char_p, []),
+    "sdv_abi_version": (C.c_int, []),
+    "sdv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_void_p]),
+    "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdv_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "sdv_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
+                            [C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdv_layernorm_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdv_conv3x3_cin_small": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
+    "sdv_conv3x3_cout_small": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
+    "sdv_latent_affine": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "sdv_slerp_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sdv_slerp_batch": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
+    "sdv_lerp_batch": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdv_cfg_ddim_step": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_int64, C.c_void_p]),
+    "sdv_latents_to_unet_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
+    "sdv_step_counter_add": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdv_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                         C.c_void_p]),
+    "sdv_linear_small": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
+    "sdv_nchw_to_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdv_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdv_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load(build_if_missing: bool = False):
+    """dlopen libsdv_hip.so and bind every symbol of include/sdv_hip.h.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        if build_if_missing:
+            from . import build as _build
+            _build.build()
+        else:
+            raise SdvHipError(
+                f"{_LIB_PATH} is missing - build it with `python -m stable_diffusion_videos_amd.build` "
+                "(there is no CPU / eager fallback for the hot path)")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = _lib.sdv_last_error().decode(errors="replace") if _lib is not None else ""
+        raise SdvHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SdvHipError(f"{name} must live in GPU memory (got device {t.device}); the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise SdvHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+_zero_pages = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return _zero_pages[key]
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM / conv
+# ------------------------------------------------------------------------------------------------
+def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, ldx: int, ldw: int,
+         ldc: int, bias: Optional[torch.Tensor] = None, bias_mode: int = 1, residual: Optional[torch.Tensor] = None,
+         ldr: int = 0, x2: Optional[torch.Tensor] = None, C1: int = 0, ldx2: int = 0, alpha: float = 1.0,
+         epi: int = 0, mode: int = 0, Hin: int = 0, Win: int = 0, Hout: int = 0, Wout: int = 0,
+         circular: bool = False, batch: int = 1, sX: int = 0, sW: int = 0, sC: int = 0, sR: int = 0,
+         step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
+         x_off: int = 0, w_off: int = 0, out_off: int = 0):
+    """Raw wrapper of ``sdv_gemm_bf16`` (element offsets x_off / w_off / out_off select sub-matrices)."""
+    lib = load()
+    a = GemmArgs()
+    a.X = _ptr(x, BF16, "X") + 2 * x_off
+    a.X2 = _ptr(x2, BF16, "X2")
+    a.W = _ptr(w, BF16, "W") + 2 * w_off
+    a.bias = _ptr(bias, F32, "bias")
+    a.R = _ptr(residual, BF16, "R")
+    a.C = _ptr(out, BF16, "C") + 2 * out_off
+    a.step_ptr = _ptr(step_ptr, torch.int32, "step_ptr")
+    a.zero_page = zero_page(x.device).data_ptr()
+    a.sX, a.sW, a.sC, a.sR = sX, sW, sC, sR
+    a.M, a.N, a.K = M, N, K
+    a.ldx, a.ldx2, a.C1, a.ldw, a.ldc, a.ldr = ldx, ldx2, C1, ldw, ldc, ldr
+    a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, Hin, Win, Hout, Wout, int(circular)
+    a.epi, a.bias_mode, a.bias_step_stride = epi, (bias_mode if bias is not None else 0), bias_step_stride
+    a.batch, a.tile, a.alpha = batch, tile, alpha
+    _check(lib.sdv_gemm_bf16(C.byref(a), _stream()), "sdv_gemm_bf16")
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, residual=None, out=None,
+           epi: int = 0, x2: Optional[torch.Tensor] = None, alpha: float = 1.0, tile: int = 0) -> torch.Tensor:
+    """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias) (+ residual); x2 = optional second K-source (concat)."""
+    M, K1 = x.shape
+    K2 = x2.shape[1] if x2 is not None else 0
+    N, K = w.shape
+    if K != K1 + K2:
+        raise SdvHipError(f"linear: K mismatch {K} vs {K1}+{K2}")
+    n_out = N // 2 if epi == 1 else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=BF16, device=x.device)
+    gemm(x, w, out, M=M, N=N, K=K, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
+         residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2, C1=K1 if x2 is not None else 0,
+         ldx2=x2.stride(0) if x2 is not None else 0, alpha=alpha, epi=epi, tile=tile)
+    return out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, nimg: int, H: int, W: int,
+            mode: int = 1, x2: Optional[torch.Tensor] = None, residual=None, circular: bool = False,
+            step_ptr=None, bias_step_stride: int = 0, out=None, tile: int = 0) -> torch.Tensor:
+    """NHWC conv3x3 pad 1.  x: [nimg*H*W, C1] (+ x2 [.., C2]); w: [Cout, 9*(C1+C2)] (OHWI).
+    mode 1: stride 1; 2: stride 2; 3: nearest-2x upsample then conv."""
+    C1 = x.shape[1]
+    C2 = x2.shape[1] if x2 is not None else 0
+    Cout = w.shape[0]
+    if w.shape[1] != 9 * (C1 + C2):
+        raise SdvHipError(f"conv3x3: weight K {w.shape[1]} != 9*{C1 + C2}")
+    if mode == 1:
+        Ho, Wo = H, W
+    elif mode == 2:
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    else:
+        Ho, Wo = 2 * H, 2 * W
+    M = nimg * Ho * Wo
+    if out is None:
+        out = torch.empty((M, Cout), dtype=BF16, device=x.device)
+    gemm(x, w, out, M=M, N=Cout, K=C1 + C2, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
+         residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2,
+         C1=C1 if x2 is not None else 0, ldx2=x2.stride(0) if x2 is not None else 0, mode=mode, Hin=H, Win=W,
+         Hout=Ho, Wout=Wo, circular=circular, step_ptr=step_ptr, bias_step_stride=bias_step_stride, tile=tile)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# attention / norms
+# ------------------------------------------------------------------------------------------------
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Lq: int,
+              Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0):
+    lib = load()
+    _check(lib.sdv_attention_bf16(_ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off,
+                                  _ptr(vt, BF16, "Vt"), _ptr(out, BF16, "O"), B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo,
+                                  scale, _stream()), "sdv_attention_bf16")
+
+
+def softmax_rows_(s: torch.Tensor, rows: int, cols: int, ld: int):
+    lib = load()
+    _check(lib.sdv_softmax_rows_bf16(_ptr(s, BF16, "S"), rows, cols, ld, _stream()), "sdv_softmax_rows_bf16")
+
+
+def gn_splits(HW: int) -> int:
+    return max(1, min(64, HW // 64))
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg: int, HW: int, groups: int,
+              eps: float, silu: bool, x2: Optional[torch.Tensor] = None, out=None) -> torch.Tensor:
+    """GroupNorm(+SiLU) over NHWC [nimg*HW, C1] (++ [.., C2] concatenated on channels) -> bf16 [.., C1+C2]."""
+    lib = load()
+    C1 = x.shape[1]
+    C2 = x2.shape[1] if x2 is not None else 0
+    splits = gn_splits(HW)
+    partials = torch.empty((nimg, splits, groups, 2), dtype=F32, device=x.device)
+    if out is None:
+        out = torch.empty((nimg * HW, C1 + C2), dtype=BF16, device=x.device)
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise SdvHipError("groupnorm: inputs must be contiguous")
+    _check(lib.sdv_groupnorm_stats(_ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), C1, C2, nimg, HW, groups, splits,
+                                   _ptr(partials), _stream()), "sdv_groupnorm_stats")
+    _check(lib.sdv_groupnorm_apply(_ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), C1, C2, nimg, HW, groups, splits,
+                                   _ptr(partials), _ptr(gamma, F32, "gamma"), _ptr(beta, F32, "beta"), eps,
+                                   int(silu), _ptr(out, BF16, "Y"), _stream()), "sdv_groupnorm_apply")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None) -> torch.Tensor:
+    lib = load()
+    rows, Cn = x.shape
+    if not x.is_contiguous():
+        raise SdvHipError("layernorm: input must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib.sdv_layernorm_bf16(_ptr(x, BF16, "X"), _ptr(gamma, F32), _ptr(beta, F32), eps, rows, Cn,
+                                  _ptr(out, BF16), _stream()), "sdv_layernorm_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# small convs / latents
+# ------------------------------------------------------------------------------------------------
+def conv3x3_cin_small(x, w, bias, *, nimg, H, W, circular=False, out=None):
+    lib = load()
+    Cin = x.shape[1]
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((nimg * H * W, Cout), dtype=BF16, device=x.device)
+    _check(lib.sdv_conv3x3_cin_small(_ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out, BF16), nimg, H,
+                                     W, Cin, Cout, int(circular), _stream()), "sdv_conv3x3_cin_small")
+    return out
+
+
+def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_u8=None, circular=False):
+    lib = load()
+    Cin = x.shape[1]
+    Cout = w.shape[0]
+    _check(lib.sdv_conv3x3_cout_small(_ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out_f32, F32),
+                                      _ptr(out_u8, torch.uint8), nimg, H, W, Cin, Cout, out_mode, int(circular),
+                                      _stream()), "sdv_conv3x3_cout_small")
+
+
+def latent_affine(x, wpq, bias, in_scale, out, npix, Cn):
+    lib = load()
+    _check(lib.sdv_latent_affine(_ptr(x, F32), _ptr(wpq, F32), _ptr(bias, F32), in_scale, _ptr(out, BF16), npix, Cn,
+                                 _stream()), "sdv_latent_affine")
+
+
+# ------------------------------------------------------------------------------------------------
+# interpolation / scheduler step
+# ------------------------------------------------------------------------------------------------
+def slerp_stats(v0, v1) -> torch.Tensor:
+    lib = load()
+    stats = torch.empty(3, dtype=torch.float64, device=v0.device)
+    _check(lib.sdv_slerp_stats(_ptr(v0, F32, "v0"), _ptr(v1, F32, "v1"), v0.numel(), _ptr(stats), _stream()),
+           "sdv_slerp_stats")
+    return stats
+
+
+def slerp_batch(v0, v1, stats, T, *, C_: int, HW: int, to_hwc: bool, dot_threshold: float = 0.9995, out=None):
+    lib = load()
+    n = T.numel()
+    if out is None:
+        out = torch.empty((n, C_ * HW), dtype=F32, device=v0.device)
+    _check(lib.sdv_slerp_batch(_ptr(v0, F32), _ptr(v1, F32), _ptr(stats, torch.float64), _ptr(T, F32), n, C_, HW,
+                               int(to_hwc), dot_threshold, _ptr(out, F32), _stream()), "sdv_slerp_batch")
+    return out
+
+
+def lerp_batch(a, b, T, *, out_f32=None, out_bf16=None):
+    lib = load()
+    _check(lib.sdv_lerp_batch(_ptr(a, F32), _ptr(b, F32), _ptr(T, F32), T.numel(), a.numel(), _ptr(out_f32, F32),
+                              _ptr(out_bf16, BF16), _stream()), "sdv_lerp_batch")
+
+
+def cfg_ddim_step(eps, latents, x2, coefs, step_ptr, noise, guidance: float, cfg: bool, n: int):
+    lib = load()
+    _check(lib.sdv_cfg_ddim_step(_ptr(eps, F32), _ptr(latents, F32), _ptr(x2, BF16), _ptr(coefs, F32),
+                                 _ptr(step_ptr, torch.int32), _ptr(noise, F32), guidance, int(cfg), n, _stream()),
+           "sdv_cfg_ddim_step")
+
+
+def latents_to_unet_input(latents, x2, cfg: bool, n: int):
+    lib = load()
+    _check(lib.sdv_latents_to_unet_input(_ptr(latents, F32), _ptr(x2, BF16), int(cfg), n, _stream()),
+           "sdv_latents_to_unet_input")
+
+
+def step_counter_add(step_ptr, inc: int = 1):
+    lib = load()
+    _check(lib.sdv_step_counter_add(_ptr(step_ptr, torch.int32), inc, _stream()), "sdv_step_counter_add")
+
+
+def timestep_embedding(ts, dim: int, flip: bool, freq_shift: float):
+    lib = load()
+    out = torch.empty((ts.numel(), dim), dtype=F32, device=ts.device)
+    _check(lib.sdv_timestep_embedding(_ptr(ts, F32), ts.numel(), dim, int(flip), freq_shift, _ptr(out), _stream()),
+           "sdv_timestep_embedding")
+    return out
+
+
+def linear_small(x, w, b=None, add=None, silu_in=False):
+    lib = load()
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=F32, device=x.device)
+    _check(lib.sdv_linear_small(_ptr(x, F32), _ptr(w, BF16), _ptr(b, F32), _ptr(add, F32), _ptr(out), M, N, K,
+                                int(silu_in), _stream()), "sdv_linear_small")
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=F32, device=x.device)
+    _check(lib.sdv_nchw_to_nhwc_f32(_ptr(x.contiguous(), F32), _ptr(out), n, c, h * w, _stream()), "sdv_nchw_to_nhwc_f32")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=F32, device=x.device)
+    _check(lib.sdv_nhwc_to_nchw_f32(_ptr(x.contiguous(), F32), _ptr(out), n, c, h * w, _stream()), "sdv_nhwc_to_nchw_f32")
+    return out
+
+
+def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _check(lib.sdv_f32_to_bf16(_ptr(x.contiguous(), F32), _ptr(out), x.numel(), _stream()), "sdv_f32_to_bf16")
+    return out

@@ -1,0 +1,117 @@
+"""Frame-sharded data parallelism for the walk.
+
+A frame is a pure function of (endpoint embeddings, endpoint noise, t, weights), so the walk is
+partitioned into contiguous blocks of frames, one block per rank, one process per GPU.  The only
+collectives are a one-time RCCL broadcast of the weights over xGMI and a barrier before the video is
+muxed; there are NO per-step collectives.  This mirrors the reference's only multi-device strategy
+(replicated params + sharded batch under ``jax.pmap``: flax_stable_diffusion_pipeline.py:568-597,
+:898-927) without its padding waste, because ranks need not run in lock-step.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    """(rank, world_size) of the initialised process group, or (0, 1)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    backend "nccl" is RCCL on ROCm.  Returns (rank, world_size, local_rank)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def partition_frames(frame_counts: Sequence[int], world_size: int, rank: int,
+                     skips: Sequence[int] = None) -> List[Tuple[int, int, int]]:
+    """Split the walk's frames into ``world_size`` contiguous blocks and return rank's share as a list of
+    ``(clip_index, first_frame, stop_frame)``.
+
+    ``frame_counts[i]`` is clip i's ``num_interpolation_steps``; ``skips[i]`` the number of leading frames
+    already on disk (resume).  Blocks are contiguous in (clip, frame) order so a rank keeps its clip
+    endpoints hot and works in full batches; sizes differ by at most one frame."""
+    skips = list(skips) if skips is not None else [0] * len(frame_counts)
+    todo = [(i, k) for i, n in enumerate(frame_counts) for k in range(skips[i], n)]
+    total = len(todo)
+    base, extra = divmod(total, world_size)
+    start = rank * base + min(rank, extra)
+    stop = start + base + (1 if rank < extra else 0)
+    mine = todo[start:stop]
+    out: List[Tuple[int, int, int]] = []
+    for clip, k in mine:
+        if out and out[-1][0] == clip and out[-1][2] == k:
+            out[-1] = (clip, out[-1][1], k + 1)
+        else:
+            out.append((clip, k, k + 1))
+    return out
+
+
+def broadcast_state_dict(sd: Dict[str, torch.Tensor], shapes: Dict[str, tuple], device, src: int = 0
+                         ) -> Dict[str, torch.Tensor]:
+    """One-time weight distribution: rank ``src`` holds ``sd``; everyone returns an identical dict.
+
+    Matrices travel as ONE packed bf16 buffer and vectors (biases, norm scales) as ONE packed fp32 buffer:
+    two large broadcasts (~1.7 GB + a few MB for the UNet) instead of ~700 small ones, which is what a
+    point-to-point xGMI fabric wants.  bf16 is what the kernels consume, so nothing is lost."""
+    rank, ws = world()
+    if ws == 1:
+        return sd
+    mats = [k for k, s in shapes.items() if len(s) > 1]
+    vecs = [k for k, s in shapes.items() if len(s) == 1]
+    n_m = sum(int(torch.tensor(shapes[k]).prod()) for k in mats)
+    n_v = sum(int(shapes[k][0]) for k in vecs)
+    use_gpu = dist.get_backend() == "nccl"
+    dev = torch.device(device) if use_gpu else torch.device("cpu")
+    buf_m = torch.empty(n_m, dtype=torch.bfloat16, device=dev)
+    buf_v = torch.empty(n_v, dtype=torch.float32, device=dev)
+    if rank == src:
+        o = 0
+        for k in mats:
+            n = sd[k].numel()
+            buf_m[o:o + n] = sd[k].reshape(-1).to(dev, torch.bfloat16)
+            o += n
+        o = 0
+        for k in vecs:
+            n = sd[k].numel()
+            buf_v[o:o + n] = sd[k].reshape(-1).to(dev, torch.float32)
+            o += n
+    dist.broadcast(buf_m, src=src)
+    dist.broadcast(buf_v, src=src)
+    out: Dict[str, torch.Tensor] = {}
+    o = 0
+    for k in mats:
+        n = int(torch.tensor(shapes[k]).prod())
+        out[k] = buf_m[o:o + n].view(*shapes[k]).float()
+        o += n
+    o = 0
+    for k in vecs:
+        n = int(shapes[k][0])
+        out[k] = buf_v[o:o + n].clone()
+        o += n
+    return out
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,587 @@
+"""``StableDiffusionWalkPipeline`` - drop-in for the reference class of the same name
+(/root/reference/stable_diffusion_videos/stable_diffusion_pipeline.py:38-858) on MI355X.
+
+Same public methods, keyword arguments, error behaviour, on-disk layout and ``prompt_config.json``;
+the arithmetic behind them runs in hand-written gfx950 HIP kernels (libsdv_hip.so) instead of
+diffusers/ATen:
+
+    walk            :556-807   orchestration, resume, prompt_config.json (kept bit-for-bit, quirks included)
+    make_clip_frames:481-554   T = linspace, batches, frame%06d.png
+    generate_inputs :457-479   lerp(text embeddings) + slerp(noise) - ONE fused launch per batch, on device
+    __call__        :191-455   CFG + 50-step DDIM loop (one hipGraph replay per step) + VAE decode + uint8
+    embed_text      :809-820   tokenizer + CLIP text encoder
+    init_noise      :822-838   seeded N(0,1) endpoints (CPU generator by default so seeds are portable)
+
+Deliberate, documented differences:
+  * endpoint noise is drawn from a CPU generator and uploaded (``noise_device="cpu"``) so the same seeds give
+    the same walk on any device and can be compared with a CPU run;
+  * slerp runs in fp32 on the GPU (the reference's numpy round trip raises on bf16, fact 5);
+  * the unconditional embedding, time-embedding tables and cross-attention K/V are computed once per call
+    instead of once per step; PNG encoding is asynchronous;
+  * frames can be sharded across ranks (torch.distributed / RCCL) - see ``parallel.py``.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+import os
+import time
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import config as cfgs
+from . import hip, parallel, weights
+from .engine import UNetEngine, VAEDecoderEngine
+from .scheduler import DDIMScheduler
+from .text import build_text_encoder, load_tokenizer
+from .utils import FrameWriter, get_timesteps_arr, make_video_pyav, numpy_to_pil
+
+logger = logging.getLogger("stable_diffusion_videos_amd")
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+class StableDiffusionPipelineOutput(dict):
+    """``outputs["images"]`` / ``outputs.images`` / ``outputs.nsfw_content_detected`` (reference :455, :548)."""
+
+    def __init__(self, images, nsfw_content_detected=None):
+        super().__init__(images=images, nsfw_content_detected=nsfw_content_detected)
+        self.images = images
+        self.nsfw_content_detected = nsfw_content_detected
+
+
+class _PendingModule:
+    """Host-side (CPU) parameters of a network before ``pipeline.to("cuda")`` builds its HIP engine."""
+
+    def __init__(self, kind: str, config, state_dict):
+        self.kind, self.config, self.state_dict = kind, config, state_dict
+        if kind == "unet":
+            self.in_channels = config.in_channels
+
+
+class StableDiffusionWalkPipeline:
+    _optional_components = ["safety_checker", "feature_extractor"]
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, safety_checker=None, feature_extractor=None,
+                 requires_safety_checker: bool = False, text_config=None):
+        if safety_checker is not None and feature_extractor is None:
+            raise ValueError("Make sure to define a feature extractor when loading StableDiffusionWalkPipeline if you "
+                             "want to use the safety checker. If you do not want to use the safety checker, you can "
+                             "pass `'safety_checker=None'` instead.")
+        # the two config patches the reference applies to the scheduler (:85-110)
+        if getattr(scheduler.config, "steps_offset", 1) != 1:
+            scheduler.config.steps_offset = 1
+        if getattr(scheduler.config, "clip_sample", False) is True:
+            scheduler.config.clip_sample = False
+        self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
+        self.safety_checker, self.feature_extractor = safety_checker, feature_extractor
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)      # :158
+        self.tiled = False
+        self.upsampler = None
+        self.noise_device = "cpu"          # portable seeds
+        self.embed_interp = "lerp"         # reference torch path lerps embeddings (:467); "slerp" = flax behaviour
+        self.use_graphs = os.environ.get("SDV_NO_GRAPH", "0") != "1"
+        self._device = torch.device("cpu")
+        self._graphs: Dict[tuple, dict] = {}
+        self._uncond_cache: Dict[str, torch.Tensor] = {}
+        self._sched_cache: Dict[tuple, tuple] = {}
+        self._writer: Optional[FrameWriter] = None
+        self.last_timings: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------------------------------
+    # construction
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, *args, tiled: bool = False, torch_dtype=None,
+                        revision=None, safety_checker=None, feature_extractor=None, vae=None, scheduler=None,
+                        device=None, arch: Optional[str] = None, synthetic_seed: int = 0, **kwargs):
+        """Build the pipeline (reference :840-858).
+
+        ``pretrained_model_name_or_path`` may be a LOCAL diffusers-layout directory (``unet/``, ``vae/``,
+        ``text_encoder/``, ``tokenizer/``); there is no network, so hub ids resolve to ``$SDV_MODEL_DIR`` when
+        that is set and otherwise to the same ARCHITECTURE with seeded synthetic weights (``arch`` in
+        {"sd14", "sd21", "tiny"}; inferred from the name).  ``tiled=True`` makes every convolution circular
+        (the reference monkey-patches nn.Conv2d; here it is a kernel flag)."""
+        name = str(pretrained_model_name_or_path or "")
+        model_dir = None
+        if name and Path(name).is_dir():
+            model_dir = Path(name)
+        elif os.environ.get("SDV_MODEL_DIR") and Path(os.environ["SDV_MODEL_DIR"]).is_dir():
+            model_dir = Path(os.environ["SDV_MODEL_DIR"])
+        if arch is None:
+            low = name.lower()
+            arch = "tiny" if "tiny" in low else ("sd21" if ("stable-diffusion-2" in low or "sd21" in low) else "sd14")
+        if torch_dtype not in (None, torch.bfloat16, torch.float16, torch.float32):
+            raise ValueError(f"unsupported torch_dtype {torch_dtype}")
+        if model_dir is not None:
+            ucfg = cfgs.unet_from_json(model_dir / "unet" / "config.json")
+            vcfg = cfgs.vae_from_json(model_dir / "vae" / "config.json")
+            tcfg = cfgs.sd21_text() if ucfg.cross_attention_dim == 1024 else cfgs.sd14_text()
+            u_sd = weights.load_component(model_dir, "unet", weights.unet_shapes(ucfg))
+            v_sd = weights.load_component(model_dir, "vae", weights.vae_decoder_shapes(vcfg))
+        else:
+            ucfg = {"sd14": cfgs.sd14_unet, "sd21": cfgs.sd21_unet, "tiny": cfgs.tiny_unet}[arch]()
+            vcfg = {"sd14": cfgs.sd_vae, "sd21": cfgs.sd_vae, "tiny": cfgs.tiny_vae}[arch]()
+            tcfg = {"sd14": cfgs.sd14_text, "sd21": cfgs.sd21_text, "tiny": cfgs.tiny_text}[arch]()
+            rank, ws = parallel.world()
+            if ws == 1 or rank == 0:
+                u_sd = weights.synthetic_state_dict(weights.unet_shapes(ucfg), seed=synthetic_seed)
+                v_sd = weights.synthetic_state_dict(weights.vae_decoder_shapes(vcfg), seed=synthetic_seed + 1)
+            else:
+                u_sd = v_sd = None       # arrives through the RCCL weight broadcast in .to(device)
+        if scheduler is None:
+            ptype = "v_prediction" if (arch == "sd21" and model_dir is None) else "epsilon"
+            if model_dir is not None and (model_dir / "scheduler" / "scheduler_config.json").exists():
+                sc = json.loads((model_dir / "scheduler" / "scheduler_config.json").read_text())
+                ptype = sc.get("prediction_type", "epsilon")
+            scheduler = DDIMScheduler(prediction_type=ptype)
+        text_encoder = build_text_encoder(tcfg, model_dir, seed=synthetic_seed + 2)
+        tokenizer = load_tokenizer(model_dir, tcfg)
+        pipe = cls(vae=vae or _PendingModule("vae", vcfg, v_sd), text_encoder=text_encoder, tokenizer=tokenizer,
+                   unet=_PendingModule("unet", ucfg, u_sd), scheduler=scheduler, safety_checker=safety_checker,
+                   feature_extractor=feature_extractor, requires_safety_checker=False, text_config=tcfg)
+        pipe.tiled = tiled
+        pipe.torch_dtype = torch_dtype or torch.bfloat16
+        if device is not None:
+            pipe.to(device)
+        return pipe
+
+    def to(self, device):
+        """Move to the GPU: (optionally RCCL-broadcast and) re-layout the weights into HBM and build the
+        HIP engines.  Only CUDA/HIP devices are accepted for the networks - there is no CPU path."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            if isinstance(self.unet, _PendingModule):
+                self.text_encoder.to(device)
+                self._device = device
+                return self
+            raise hip.SdvHipError("the HIP engines cannot be moved off the GPU")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        hip.load()
+        if isinstance(self.unet, _PendingModule):
+            u, v = self.unet, self.vae
+            u_shapes = weights.unet_shapes(u.config)
+            u_sd = parallel.broadcast_state_dict(u.state_dict, u_shapes, device)
+            self.unet = UNetEngine(u.config, u_sd, device, tiled=self.tiled)
+            del u_sd
+            u.state_dict = None
+            if isinstance(v, _PendingModule):
+                v_shapes = weights.vae_decoder_shapes(v.config)
+                v_sd = parallel.broadcast_state_dict(v.state_dict, v_shapes, device)
+                self.vae = VAEDecoderEngine(v.config, v_sd, device, tiled=self.tiled)
+                v.state_dict = None
+        self.text_encoder.to(device)
+        self._device = device
+        self._uncond_cache.clear()
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def enable_attention_slicing(self, slice_size: Optional[Union[str, int]] = "auto"):
+        """Accepted for API compatibility (reference :161-181).  The HIP attention kernel is flash-style and
+        never materialises the score matrix, so there is nothing to slice."""
+        self._attention_slice = slice_size
+
+    def disable_attention_slicing(self):
+        self.enable_attention_slicing(None)
+
+    def progress_bar(self, iterable):
+        return iterable
+
+    @staticmethod
+    def numpy_to_pil(images):
+        return numpy_to_pil(images)
+
+    # ------------------------------------------------------------------------------------------
+    # text / noise endpoints
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def embed_text(self, text, negative_prompt=None):
+        """Helper to embed some text (reference :809-820) -> fp32 (1, 77, D) on the pipeline device."""
+        text_input = self.tokenizer(text, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                    truncation=True, return_tensors="pt")
+        return self.text_encoder(text_input.input_ids.to(self.device))[0]
+
+    def init_noise(self, seed, noise_shape, dtype=torch.float32):
+        """Helper to initialize noise (reference :822-838)."""
+        if self.noise_device == "cpu" or self.device.type != "cuda":
+            g = torch.Generator(device="cpu").manual_seed(int(seed))
+            return torch.randn(noise_shape, generator=g, dtype=dtype, device="cpu").to(self.device)
+        g = torch.Generator(device=self.device).manual_seed(int(seed))
+        return torch.randn(noise_shape, generator=g, dtype=dtype, device=self.device)
+
+    def _uncond_embeddings(self, negative_prompt, batch_size: int) -> torch.Tensor:
+        if negative_prompt is None:
+            toks = [""]
+        elif isinstance(negative_prompt, str):
+            toks = [negative_prompt]
+        elif batch_size != len(negative_prompt):
+            raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                             f" has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                             " the batch size of `prompt`.")
+        else:
+            toks = list(negative_prompt)
+        key = "\x00".join(toks)
+        if key not in self._uncond_cache:
+            ids = self.tokenizer(toks, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                 truncation=True, return_tensors="pt").input_ids
+            with torch.no_grad():
+                self._uncond_cache[key] = self.text_encoder(ids.to(self.device))[0].float()
+        u = self._uncond_cache[key]
+        return u.repeat(batch_size, 1, 1) if u.shape[0] == 1 else u
+
+    # ------------------------------------------------------------------------------------------
+    # the denoise + decode call
+    # ------------------------------------------------------------------------------------------
+    def _schedule(self, num_inference_steps: int, eta: float):
+        self.scheduler.set_timesteps(num_inference_steps)
+        ts = tuple(int(t) for t in self.scheduler.timesteps)
+        key = (ts, float(eta), self.scheduler.config.prediction_type)
+        if key not in self._sched_cache:
+            coefs = self.scheduler.coefficient_table(eta).to(self.device)
+            self.unet.prepare_timesteps(ts)
+            tables = [r.bias_table for r in self.unet.res]
+            self._sched_cache[key] = (coefs, tables)
+        coefs, tables = self._sched_cache[key]
+        for r, t in zip(self.unet.res, tables):
+            r.bias_table = t
+        return key, coefs, len(ts)
+
+    def _graph_entry(self, key: tuple, nimg: int, B: int, h: int, w: int, cfg: bool, guidance: float, coefs, eta_noise):
+        """Static buffers + a captured hipGraph of ONE denoise step (UNet forward + CFG/DDIM update + step++)."""
+        if key in self._graphs:
+            return self._graphs[key]
+        dev = self.device
+        C = self.unet.cfg.in_channels
+        ent = {
+            "latents": torch.zeros((B, h, w, C), dtype=F32, device=dev),
+            "x2": torch.zeros((nimg * h * w, C), dtype=BF16, device=dev),
+            "step": torch.zeros(1, dtype=torch.int32, device=dev),
+            "graph": None,
+        }
+        self.unet.reserve(nimg, h, w)
+        n = B * h * w * C
+
+        def one_step():
+            eps = self.unet.forward(ent["x2"], nimg, h, w, ent["step"])
+            hip.cfg_ddim_step(eps, ent["latents"], ent["x2"], coefs, ent["step"], eta_noise, guidance, cfg, n)
+            hip.step_counter_add(ent["step"], 1)
+
+        ent["one_step"] = one_step
+        if self.use_graphs:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one_step()                       # warm-up: lazy allocations / attribute sets happen here
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            ent["graph"] = g
+        self._graphs[key] = ent
+        return ent
+
+    @torch.no_grad()
+    def __call__(self, prompt: Optional[Union[str, List[str]]] = None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt: Optional[Union[str, List[str]]] = None, num_images_per_prompt: Optional[int] = 1,
+                 eta: float = 0.0, generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: Optional[int] = 1,
+                 text_embeddings: Optional[torch.Tensor] = None, **kwargs):
+        """Same contract as the reference ``__call__`` (:191-455)."""
+        if isinstance(self.unet, _PendingModule):
+            raise hip.SdvHipError("call pipeline.to('cuda') first: the hot path only exists as HIP kernels")
+        t_start = time.perf_counter()
+        height = height or self.unet.config.sample_size * self.vae_scale_factor                 # :268
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        if height % 8 != 0 or width % 8 != 0:                                                      # :271
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (not isinstance(callback_steps, int) or callback_steps <= 0):  # :274
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type"
+                             f" {type(callback_steps)}.")
+        prompt_given = text_embeddings is None
+        if text_embeddings is None:
+            if isinstance(prompt, str):
+                batch_size = 1
+            elif isinstance(prompt, list):
+                batch_size = len(prompt)
+            else:
+                raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")    # :288
+            text_inputs = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                         return_tensors="pt")
+            ids = text_inputs.input_ids
+            if ids.shape[-1] > self.tokenizer.model_max_length:                                  # :299
+                removed = self.tokenizer.batch_decode(ids[:, self.tokenizer.model_max_length:])
+                print("The following part of your input was truncated because CLIP can only handle sequences up to"
+                      f" {self.tokenizer.model_max_length} tokens: {removed}")
+                ids = ids[:, : self.tokenizer.model_max_length]
+            text_embeddings = self.text_encoder(ids.to(self.device))[0]
+        else:
+            batch_size = text_embeddings.shape[0]                                                 # :308
+        text_embeddings = text_embeddings.to(self.device, F32)
+        bs_embed, seq_len, _ = text_embeddings.shape
+        text_embeddings = text_embeddings.repeat(1, num_images_per_prompt, 1).view(bs_embed * num_images_per_prompt,
+                                                                                   seq_len, -1)
+        do_cfg = guidance_scale > 1.0                                                             # :318
+        if do_cfg:
+            if negative_prompt is not None and prompt_given and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")                                             # :325
+            uncond = self._uncond_embeddings(negative_prompt, batch_size)
+            if num_images_per_prompt != 1:
+                uncond = uncond.repeat(1, num_images_per_prompt, 1).view(batch_size * num_images_per_prompt, seq_len, -1)
+            ctx = torch.cat([uncond, text_embeddings])                                            # :358
+        else:
+            ctx = text_embeddings
+        B = batch_size * num_images_per_prompt
+        C = self.unet.in_channels
+        h, w = height // 8, width // 8
+        latents_shape = (B, C, h, w)                                                              # :365-370
+        if latents is None:
+            gdev = generator.device if generator is not None else torch.device("cpu")
+            latents = torch.randn(latents_shape, generator=generator, device=gdev, dtype=F32)
+        elif tuple(latents.shape) != latents_shape:
+            raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {latents_shape}")   # :390
+        latents = latents.to(self.device, F32)
+
+        sched_key, coefs, nsteps = self._schedule(num_inference_steps, eta)                       # :394
+        nimg = 2 * B if do_cfg else B
+        eta_noise = None
+        if eta > 0:
+            gdev = generator.device if generator is not None else torch.device("cpu")
+            eta_noise = torch.randn((nsteps, B, h, w, C), generator=generator, device=gdev, dtype=F32).to(self.device)
+        self.unet.prepare_context(ctx)
+        gkey = (sched_key, nimg, h, w, do_cfg, float(guidance_scale), eta > 0)
+        ent = self._graph_entry(gkey, nimg, B, h, w, do_cfg, float(guidance_scale), coefs, eta_noise)
+        if eta > 0:
+            ent.setdefault("noise", eta_noise)
+            if ent["noise"] is not eta_noise:
+                ent["noise"].copy_(eta_noise)
+
+        lat_nhwc = hip.nchw_to_nhwc(latents * self.scheduler.init_noise_sigma)                    # :401
+        ent["latents"].copy_(lat_nhwc)
+        ent["step"].zero_()
+        hip.latents_to_unet_input(ent["latents"], ent["x2"], do_cfg, ent["latents"].numel())     # :414
+        t_prep = time.perf_counter()
+        for i in range(nsteps):                                                                   # :412
+            if ent["graph"] is not None:
+                ent["graph"].replay()
+            else:
+                ent["one_step"]()
+            if callback is not None and i % callback_steps == 0:                                  # :429
+                callback(i, int(self.scheduler.timesteps[i]), hip.nhwc_to_nchw(ent["latents"]))
+        if kwargs.get("return_latents", False):
+            return hip.nhwc_to_nchw(ent["latents"])
+        want_float = output_type != "pil"
+        u8, f32 = self.vae.decode(ent["latents"], want_float=want_float)                         # :432-435
+        if want_float:
+            image = f32.cpu().numpy()                                                             # :438
+        else:
+            image = u8.cpu().numpy()
+        t_done = time.perf_counter()
+        self.last_timings = {"prepare_s": t_prep - t_start, "denoise_decode_s": t_done - t_prep, "frames": B}
+        has_nsfw = None
+        if self.safety_checker is not None:
+            raise NotImplementedError("safety_checker is outside the hot path; pass safety_checker=None")
+        if output_type == "pil":
+            image = numpy_to_pil(image)                                                           # :450
+        if not return_dict:
+            return (image, has_nsfw)
+        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=has_nsfw)
+
+    # ------------------------------------------------------------------------------------------
+    # interpolation + clip generation
+    # ------------------------------------------------------------------------------------------
+    def generate_inputs(self, prompt_a, prompt_b, seed_a, seed_b, noise_shape, T, batch_size):
+        """Reference :457-479.  Yields ``(batch_idx, embeds (b,77,D), noise (b,C,h,w))``; every batch is ONE
+        lerp launch + ONE slerp launch over all its frames (the whole-tensor dot/norms of utils.py:51 are
+        per-clip constants and are reduced once)."""
+        embeds_a = self.embed_text(prompt_a).float().contiguous()
+        embeds_b = self.embed_text(prompt_b).float().contiguous()
+        latents_a = self.init_noise(seed_a, noise_shape, F32).contiguous()
+        latents_b = self.init_noise(seed_b, noise_shape, F32).contiguous()
+        T = np.asarray(T)
+        if embeds_a.is_cuda:
+            stats = hip.slerp_stats(latents_a, latents_b)
+            e_stats = hip.slerp_stats(embeds_a, embeds_b) if self.embed_interp == "slerp" else None
+        batch_idx = 0
+        _, Cc, hh, ww = noise_shape
+        for s in range(0, T.shape[0], batch_size):
+            tb = torch.tensor(np.asarray(T[s:s + batch_size], dtype=np.float64), dtype=F32, device=self.device)
+            n = tb.numel()
+            embeds = torch.empty((n,) + tuple(embeds_a.shape[1:]), dtype=F32, device=self.device)
+            if self.embed_interp == "slerp":
+                hip.slerp_batch(embeds_a, embeds_b, e_stats, tb, C_=1, HW=embeds_a.numel(), to_hwc=False, out=embeds)
+            else:
+                hip.lerp_batch(embeds_a, embeds_b, tb, out_f32=embeds)                          # :467
+            noise = hip.slerp_batch(latents_a, latents_b, stats, tb, C_=1, HW=latents_a.numel(), to_hwc=False)  # :468
+            yield batch_idx, embeds, noise.view(n, Cc, hh, ww)
+            batch_idx += 1
+
+    def make_clip_frames(self, prompt_a: str, prompt_b: str, seed_a: int, seed_b: int, num_interpolation_steps: int = 5,
+                         save_path: Union[str, Path] = "outputs/", num_inference_steps: int = 50,
+                         guidance_scale: float = 7.5, eta: float = 0.0, height: Optional[int] = None,
+                         width: Optional[int] = None, upsample: bool = False, batch_size: int = 1,
+                         image_file_ext: str = ".png", T: np.ndarray = None, skip: int = 0, negative_prompt: str = None,
+                         step: Optional[Tuple[int, int]] = None, stop: Optional[int] = None):
+        """Reference :481-554 (``stop`` is the extra upper frame bound used for frame sharding)."""
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        save_path = Path(save_path)
+        save_path.mkdir(parents=True, exist_ok=True)
+        T = T if T is not None else np.linspace(0.0, 1.0, num_interpolation_steps)             # :509
+        if T.shape[0] != num_interpolation_steps:                                                # :510
+            raise ValueError(f"Unexpected T shape, got {T.shape}, expected dim 0 to be {num_interpolation_steps}")
+        if upsample:
+            if getattr(self, "upsampler", None) is None:
+                from .upsampling import RealESRGANModel
+                self.upsampler = RealESRGANModel.from_pretrained("nateraw/real-esrgan")
+            self.upsampler.to(self.device)
+        stop = num_interpolation_steps if stop is None else stop
+        batch_generator = self.generate_inputs(prompt_a, prompt_b, seed_a, seed_b,
+                                               (1, self.unet.in_channels, height // 8, width // 8), T[skip:stop],
+                                               batch_size)
+        num_batches = math.ceil(num_interpolation_steps / batch_size)
+        log_prefix = "" if step is None else f"[{step[0]}/{step[1]}] "
+        writer = self._writer or FrameWriter()
+        frame_index = skip
+        for batch_idx, embeds_batch, noise_batch in batch_generator:
+            if batch_size == 1:
+                msg = f"Generating frame {frame_index}"
+            else:
+                msg = f"Generating frames {frame_index}-{frame_index + embeds_batch.shape[0] - 1}"
+            logger.info(f"{log_prefix}[{batch_idx}/{num_batches}] {msg}")
+            outputs = self(latents=noise_batch, text_embeddings=embeds_batch, height=height, width=width,
+                           guidance_scale=guidance_scale, eta=eta, num_inference_steps=num_inference_steps,
+                           output_type="pil" if not upsample else "numpy", negative_prompt=negative_prompt)["images"]
+            for image in outputs:
+                frame_filepath = save_path / (f"frame%06d{image_file_ext}" % frame_index)
+                writer.submit(image, frame_filepath, self.upsampler if upsample else None)      # :552-553
+                frame_index += 1
+        if self._writer is None:
+            writer.close()
+
+    def walk(self, prompts: Optional[List[str]] = None, seeds: Optional[List[int]] = None,
+             num_interpolation_steps: Optional[Union[int, List[int]]] = 5, output_dir: Optional[str] = "./dreams",
+             name: Optional[str] = None, image_file_ext: Optional[str] = ".png", fps: Optional[int] = 30,
+             num_inference_steps: Optional[int] = 50, guidance_scale: Optional[float] = 7.5, eta: Optional[float] = 0.0,
+             height: Optional[int] = None, width: Optional[int] = None, upsample: Optional[bool] = False,
+             batch_size: Optional[int] = 1, resume: Optional[bool] = False, audio_filepath: str = None,
+             audio_start_sec: Optional[Union[int, float]] = None, margin: Optional[float] = 1.0,
+             smooth: Optional[float] = 0.0, negative_prompt: Optional[str] = None, make_video: Optional[bool] = True):
+        """Generate the frames (and video) of a walk through ``prompts`` / ``seeds`` - reference :556-807.
+
+        Output layout (identical to the reference docstring :648-666):
+            {output_dir}/{name}/prompt_config.json
+            {output_dir}/{name}/{name}_{i:06d}/frame{k:06d}{ext}   and   .../{name}_{i:06d}.mp4
+            {output_dir}/{name}/{name}.mp4
+        With torch.distributed initialised the frames are sharded over the ranks (``parallel.py``); rank 0
+        writes the config and muxes the video.  Returns the video path, or None when ``make_video=False``."""
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        rank, world_size = parallel.world()
+        output_path = Path(output_dir)
+        name = name or time.strftime("%Y%m%d-%H%M%S")
+        save_path_root = output_path / name
+        save_path_root.mkdir(parents=True, exist_ok=True)
+        output_filepath = save_path_root / f"{name}.mp4"
+        if not resume and isinstance(num_interpolation_steps, int):
+            num_interpolation_steps = [num_interpolation_steps] * (len(prompts) - 1)            # :685-686
+        if not resume:
+            audio_start_sec = audio_start_sec or 0
+        prompt_config_path = save_path_root / "prompt_config.json"
+        if not resume:
+            if rank == 0:
+                prompt_config_path.write_text(json.dumps(dict(
+                    prompts=prompts, seeds=seeds, num_interpolation_steps=num_interpolation_steps, fps=fps,
+                    num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, eta=eta, upsample=upsample,
+                    height=height, width=width, audio_filepath=audio_filepath, audio_start_sec=audio_start_sec,
+                    negative_prompt=negative_prompt), indent=2, sort_keys=False))              # :694-714
+        else:
+            data = json.load(open(prompt_config_path))                                           # :716-729
+            prompts = data["prompts"]
+            seeds = data["seeds"]
+            num_interpolation_steps = data["num_interpolation_steps"]
+            fps = data["fps"]
+            num_inference_steps = data["num_inference_steps"]
+            guidance_scale = data["guidance_scale"]
+            eta = data["eta"]
+            upsample = data["upsample"]
+            height = data["height"]
+            width = data["width"]
+            audio_filepath = data["audio_filepath"]
+            audio_start_sec = data["audio_start_sec"]
+            negative_prompt = data.get("negative_prompt", None)
+
+        # pass 1: what has to be generated (resume logic :741-753, quirk at :750 kept)
+        clips = []
+        for i, (prompt_a, prompt_b, seed_a, seed_b, num_step) in enumerate(
+                zip(prompts, prompts[1:], seeds, seeds[1:], num_interpolation_steps)):
+            save_path = save_path_root / f"{name}_{i:06d}"
+            step_output_filepath = save_path / f"{name}_{i:06d}.mp4"
+            skip = 0
+            if resume:
+                if step_output_filepath.exists():
+                    print(f"Skipping {save_path} because frames already exist")
+                    continue
+                existing_frames = sorted(save_path.glob(f"*{image_file_ext}"))
+                if existing_frames:
+                    skip = int(existing_frames[-1].stem[-6:]) + 1
+                    if skip + 1 >= num_step:
+                        print(f"Skipping {save_path} because frames already exist")
+                        continue
+                    print(f"Resuming {save_path.name} from frame {skip}")
+            clips.append(dict(i=i, prompt_a=prompt_a, prompt_b=prompt_b, seed_a=seed_a, seed_b=seed_b,
+                              num_step=num_step, skip=skip, save_path=save_path, mp4=step_output_filepath))
+        if world_size > 1:
+            parallel.barrier()      # every rank has looked at the directory before anyone writes new frames
+        shares = parallel.partition_frames([c["num_step"] for c in clips], world_size, rank, [c["skip"] for c in clips])
+
+        # pass 2: generate this rank's frames
+        self._writer = FrameWriter()
+        try:
+            for ci, first, stop in shares:
+                c = clips[ci]
+                i, num_step = c["i"], c["num_step"]
+                audio_offset = audio_start_sec + sum(num_interpolation_steps[:i]) / fps          # :755
+                audio_duration = num_step / fps
+                self.make_clip_frames(
+                    c["prompt_a"], c["prompt_b"], c["seed_a"], c["seed_b"], num_interpolation_steps=num_step,
+                    save_path=c["save_path"], num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                    eta=eta, height=height, width=width, upsample=upsample, batch_size=batch_size,
+                    T=get_timesteps_arr(audio_filepath, offset=audio_offset, duration=audio_duration, fps=fps,
+                                        margin=margin, smooth=smooth) if audio_filepath else None,
+                    skip=first, stop=stop, negative_prompt=negative_prompt, step=(i, len(prompts) - 1))
+        finally:
+            self._writer.close()
+            self._writer = None
+        if world_size > 1:
+            parallel.barrier()      # all frames are on disk before rank 0 muxes
+        if not make_video:
+            return None
+        result = None
+        if rank == 0:
+            for c in clips:
+                i, num_step = c["i"], c["num_step"]
+                audio_offset = audio_start_sec + sum(num_interpolation_steps[:i]) / fps
+                make_video_pyav(c["save_path"], audio_filepath=audio_filepath, fps=fps, output_filepath=c["mp4"],
+                                glob_pattern=f"*{image_file_ext}", audio_offset=audio_offset,
+                                audio_duration=num_step / fps, sr=44100)                        # :787-796
+            result = make_video_pyav(save_path_root, audio_filepath=audio_filepath, fps=fps, audio_offset=audio_start_sec,
+                                     audio_duration=sum(num_interpolation_steps) / fps, output_filepath=output_filepath,
+                                     glob_pattern=f"**/*{image_file_ext}", sr=44100)             # :798-807
+        if world_size > 1:
+            parallel.barrier()
+            result = str(output_filepath) if result is None else result
+        return result

@@ -1,0 +1,240 @@
+"""Parameter tables for the hot-path networks: shapes in the diffusers state-dict schema
+(SURVEY.md section 8a), seeded synthetic initialisation (there are no checkpoints offline), loading of
+a local diffusers-layout model directory (``SDV_MODEL_DIR`` / ``from_pretrained(<dir>)``), and the
+one-time re-layout of the weights for the HIP kernels (OHWI conv filters, fused QK, GEGLU row
+interleave, bf16)."""
+from __future__ import annotations
+
+import json
+import math
+from collections import OrderedDict
+from pathlib import Path
+from typing import Dict, Optional
+
+import torch
+
+from .config import UNetConfig, VAEConfig
+
+StateDict = Dict[str, torch.Tensor]
+
+
+# ------------------------------------------------------------------------------------------------
+# shape tables (key -> shape), diffusers naming
+# ------------------------------------------------------------------------------------------------
+def _conv(sd, name, cin, cout, k):
+    sd[name + ".weight"] = (cout, cin, k, k)
+    sd[name + ".bias"] = (cout,)
+
+
+def _lin(sd, name, cin, cout, bias=True):
+    sd[name + ".weight"] = (cout, cin)
+    if bias:
+        sd[name + ".bias"] = (cout,)
+
+
+def _norm(sd, name, c):
+    sd[name + ".weight"] = (c,)
+    sd[name + ".bias"] = (c,)
+
+
+def _resnet(sd, p, cin, cout, temb):
+    _norm(sd, p + ".norm1", cin)
+    _conv(sd, p + ".conv1", cin, cout, 3)
+    if temb:
+        _lin(sd, p + ".time_emb_proj", temb, cout)
+    _norm(sd, p + ".norm2", cout)
+    _conv(sd, p + ".conv2", cout, cout, 3)
+    if cin != cout:
+        _conv(sd, p + ".conv_shortcut", cin, cout, 1)
+
+
+def _transformer(sd, p, c, ctx, linear_proj):
+    _norm(sd, p + ".norm", c)
+    if linear_proj:
+        _lin(sd, p + ".proj_in", c, c)
+    else:
+        _conv(sd, p + ".proj_in", c, c, 1)
+    b = p + ".transformer_blocks.0"
+    _norm(sd, b + ".norm1", c)
+    for a, kd in (("attn1", c), ("attn2", ctx)):
+        _lin(sd, f"{b}.{a}.to_q", c, c, bias=False)
+        _lin(sd, f"{b}.{a}.to_k", kd, c, bias=False)
+        _lin(sd, f"{b}.{a}.to_v", kd, c, bias=False)
+        _lin(sd, f"{b}.{a}.to_out.0", c, c)
+        if a == "attn1":
+            _norm(sd, b + ".norm2", c)
+    _norm(sd, b + ".norm3", c)
+    _lin(sd, b + ".ff.net.0.proj", c, 8 * c)
+    _lin(sd, b + ".ff.net.2", 4 * c, c)
+    if linear_proj:
+        _lin(sd, p + ".proj_out", c, c)
+    else:
+        _conv(sd, p + ".proj_out", c, c, 1)
+
+
+def unet_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
+    sd: "OrderedDict[str, tuple]" = OrderedDict()
+    ch = cfg.block_out_channels
+    temb = cfg.temb_dim
+    ctx = cfg.cross_attention_dim
+    lp = cfg.use_linear_projection
+    _conv(sd, "conv_in", cfg.in_channels, ch[0], 3)
+    _lin(sd, "time_embedding.linear_1", ch[0], temb)
+    _lin(sd, "time_embedding.linear_2", temb, temb)
+    cout = ch[0]
+    for i, typ in enumerate(cfg.down_block_types):
+        cin, cout = cout, ch[i]
+        for j in range(cfg.layers_per_block):
+            _resnet(sd, f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, temb)
+            if typ.startswith("CrossAttn"):
+                _transformer(sd, f"down_blocks.{i}.attentions.{j}", cout, ctx, lp)
+        if i != len(ch) - 1:
+            _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+    c = ch[-1]
+    _resnet(sd, "mid_block.resnets.0", c, c, temb)
+    _transformer(sd, "mid_block.attentions.0", c, ctx, lp)
+    _resnet(sd, "mid_block.resnets.1", c, c, temb)
+    rev = list(reversed(ch))
+    cout = rev[0]
+    for i, typ in enumerate(cfg.up_block_types):
+        prev, cout = cout, rev[i]
+        cin = rev[min(i + 1, len(ch) - 1)]
+        n = cfg.layers_per_block + 1
+        for j in range(n):
+            skip = cin if j == n - 1 else cout
+            rin = prev if j == 0 else cout
+            _resnet(sd, f"up_blocks.{i}.resnets.{j}", rin + skip, cout, temb)
+            if typ.startswith("CrossAttn"):
+                _transformer(sd, f"up_blocks.{i}.attentions.{j}", cout, ctx, lp)
+        if i != len(ch) - 1:
+            _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
+    _norm(sd, "conv_norm_out", ch[0])
+    _conv(sd, "conv_out", ch[0], cfg.out_channels, 3)
+    return sd
+
+
+def vae_decoder_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
+    sd: "OrderedDict[str, tuple]" = OrderedDict()
+    ch = list(reversed(cfg.block_out_channels))
+    _conv(sd, "post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+    _conv(sd, "decoder.conv_in", cfg.latent_channels, ch[0], 3)
+    _resnet(sd, "decoder.mid_block.resnets.0", ch[0], ch[0], None)
+    a = "decoder.mid_block.attentions.0"
+    _norm(sd, a + ".group_norm", ch[0])
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        _lin(sd, f"{a}.{n}", ch[0], ch[0])
+    _resnet(sd, "decoder.mid_block.resnets.1", ch[0], ch[0], None)
+    cout = ch[0]
+    for i in range(len(ch)):
+        cin, cout = cout, ch[i]
+        for j in range(cfg.layers_per_block + 1):
+            _resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, None)
+        if i != len(ch) - 1:
+            _conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
+    _norm(sd, "decoder.conv_norm_out", ch[-1])
+    _conv(sd, "decoder.conv_out", ch[-1], cfg.out_channels, 3)
+    return sd
+
+
+def count_params(shapes) -> int:
+    return sum(math.prod(s) for s in shapes.values())
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic initialisation (seeded, CPU generator -> identical on every rank / machine)
+# ------------------------------------------------------------------------------------------------
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def synthetic_state_dict(shapes, seed: int = 0, bf16_exact: bool = True) -> StateDict:
+    """Variance-preserving random weights: matrices ~ N(0, 1/fan_in), biases ~ N(0, 0.02^2), norm scales
+    1 + 0.1 N, norm shifts 0.1 N.  With ``bf16_exact`` every matrix entry is bf16-representable, so
+    the bf16 HIP path and an fp32 checker can share bit-identical weights."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out: StateDict = OrderedDict()
+    for name, shape in shapes.items():
+        is_norm = "norm" in name.split(".")[-2]
+        if len(shape) == 1:
+            v = torch.randn(shape, generator=g)
+            if is_norm and name.endswith(".weight"):
+                t = 1.0 + 0.1 * v
+            elif is_norm:
+                t = 0.1 * v
+            else:
+                t = 0.02 * v
+        else:
+            fan_in = math.prod(shape[1:])
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+            if bf16_exact:
+                t = bf16_round(t)
+        out[name] = t
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# local checkpoint loading (diffusers directory layout, safetensors or torch .bin)
+# ------------------------------------------------------------------------------------------------
+_VAE_OLD_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def _load_file(path: Path) -> StateDict:
+    if path.suffix == ".safetensors":
+        from safetensors.torch import load_file
+        return load_file(str(path))
+    return torch.load(str(path), map_location="cpu", weights_only=True)
+
+
+def load_component(model_dir: Path, sub: str, shapes, prefix_filter: Optional[str] = None) -> StateDict:
+    d = Path(model_dir) / sub
+    cands = [d / "diffusion_pytorch_model.safetensors", d / "diffusion_pytorch_model.fp16.safetensors",
+             d / "diffusion_pytorch_model.bin", d / "model.safetensors", d / "pytorch_model.bin"]
+    path = next((p for p in cands if p.exists()), None)
+    if path is None:
+        raise FileNotFoundError(f"no weights under {d}")
+    raw = _load_file(path)
+    sd: StateDict = OrderedDict()
+    for k, v in raw.items():
+        for old, new in _VAE_OLD_ATTN.items():
+            k = k.replace(f".attentions.0.{old}.", f".attentions.0.{new}.")
+        sd[k] = v
+    missing = [k for k in shapes if k not in sd]
+    if missing:
+        raise KeyError(f"{path}: missing keys, e.g. {missing[:4]}")
+    out: StateDict = OrderedDict()
+    for k, shape in shapes.items():
+        t = sd[k].float()
+        if tuple(t.shape) != tuple(shape):
+            if t.numel() == math.prod(shape):
+                t = t.reshape(shape)     # e.g. linear-vs-1x1-conv projections
+            else:
+                raise ValueError(f"{k}: shape {tuple(t.shape)} != expected {shape}")
+        out[k] = t
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# re-layout for the kernels
+# ------------------------------------------------------------------------------------------------
+def conv_w(w: torch.Tensor, device) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin] (OHWI, K-contiguous rows) bf16."""
+    co = w.shape[0]
+    return w.permute(0, 2, 3, 1).reshape(co, -1).contiguous().to(device=device, dtype=torch.bfloat16)
+
+
+def lin_w(w: torch.Tensor, device) -> torch.Tensor:
+    return w.reshape(w.shape[0], -1).contiguous().to(device=device, dtype=torch.bfloat16)
+
+
+def vec(v: torch.Tensor, device) -> torch.Tensor:
+    return v.contiguous().to(device=device, dtype=torch.float32)
+
+
+def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
+    """ff.net.0.proj rows are [value(4C) | gate(4C)]; the GEGLU epilogue wants 32-row blocks
+    [value_b | gate_b] so that both halves of a channel meet in the same MFMA lane/register."""
+    half = t.shape[0] // 2
+    assert half % 32 == 0
+    val = t[:half].reshape(half // 32, 32, *t.shape[1:])
+    gate = t[half:].reshape(half // 32, 32, *t.shape[1:])
+    return torch.stack([val, gate], dim=1).reshape(t.shape).contiguous()

@@ -1,0 +1,184 @@
+"""CPU tests of the host side: the C ABI loads and exports every symbol include/sdv_hip.h declares,
+weight schema / re-layout, the scheduler's fused coefficients, frame partitioning, tokenizer stub, and
+that the product path fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_c_abi_exports_every_declared_symbol(hip):
+    header = (ROOT / "include" / "sdv_hip.h").read_text()
+    declared = set(re.findall(r"\b(sdv_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sdv_gemm_args"}
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(str(hip.lib_path()))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libsdv_hip.so does not export {name}"
+    assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
+    assert hip.load().sdv_abi_version() == 1
+
+
+def test_gemm_args_struct_matches_header(hip):
+    """Field order of the ctypes mirror == field order of struct sdv_gemm_args in the header."""
+    header = (ROOT / "include" / "sdv_hip.h").read_text()
+    body = header[header.index("typedef struct sdv_gemm_args {"):header.index("} sdv_gemm_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for stmt in body.split("{", 1)[1].split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        decl = stmt.split()
+        rest = stmt[len(decl[0]):] if decl[0] != "const" else stmt[len("const " + decl[1]):]
+        names += [n.strip(" *") for n in rest.split(",")]
+    assert names == [f[0] for f in hip.GemmArgs._fields_]
+
+
+def test_argument_validation_without_gpu(hip):
+    """Host-side argument checks run before any launch, so they are testable without a GPU."""
+    lib = hip.load()
+    a = hip.GemmArgs()
+    assert lib.sdv_gemm_bf16(ctypes.byref(a), None) == -1
+    assert b"null operand" in lib.sdv_last_error()
+    a.X = a.W = a.C = 1
+    a.M = a.N = 64
+    a.K = 96
+    assert lib.sdv_gemm_bf16(ctypes.byref(a), None) == -1 and b"multiple of 64" in lib.sdv_last_error()
+    assert lib.sdv_attention_bf16(1, 1, 1, 1, 1, 1, 64, 64, 48, 64, 64, 64, 64, 1.0, None) == -1
+    assert b"unsupported head dim" in lib.sdv_last_error()
+
+
+def test_product_fails_loudly_without_gpu(hip):
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline, slerp
+    with pytest.raises(hip.SdvHipError, match="GPU"):
+        hip.linear(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+    with pytest.raises(hip.SdvHipError):
+        slerp(0.5, torch.zeros(4), torch.ones(4))
+    if not torch.cuda.is_available():
+        pipe = StableDiffusionWalkPipeline.from_pretrained("tiny")
+        with pytest.raises(hip.SdvHipError, match="cuda"):
+            pipe(prompt="a cat", height=64, width=64)
+
+
+def test_product_never_imports_oracle():
+    for py in (ROOT / "stable_diffusion_videos_amd").glob("*.py"):
+        src = py.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), py
+        assert "from oracle" not in src and "import oracle" not in src, py
+
+
+def test_weight_schema_and_relayout():
+    from stable_diffusion_videos_amd import config, weights
+    shapes = weights.unet_shapes(config.sd14_unet())
+    assert weights.count_params(shapes) == 859_520_964 and len(shapes) == 686
+    assert weights.count_params(weights.unet_shapes(config.sd21_unet())) == 865_910_724
+    assert weights.count_params(weights.vae_decoder_shapes(config.sd_vae())) == 49_490_199
+    assert shapes["up_blocks.1.resnets.2.conv1.weight"] == (1280, 1920, 3, 3)
+    assert shapes["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (320, 768)
+    sd = weights.synthetic_state_dict(weights.unet_shapes(config.tiny_unet()), seed=3)
+    sd2 = weights.synthetic_state_dict(weights.unet_shapes(config.tiny_unet()), seed=3)
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+    w = sd["conv_in.weight"]
+    assert torch.equal(w, w.to(torch.bfloat16).float())          # bf16-exact
+    assert abs(float(sd["conv_norm_out.weight"].mean()) - 1.0) < 0.1
+    # OHWI relayout: row n, column (ky*3+kx)*Cin + c
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    r = weights.conv_w(w, "cpu").float()
+    assert r.shape == (2, 27) and float(r[1, (2 * 3 + 1) * 3 + 2]) == float(w[1, 2, 2, 1])
+    # GEGLU interleave: 32-row blocks [value_b | gate_b]
+    t = torch.arange(128, dtype=torch.float32)[:, None].repeat(1, 2)
+    g = weights.geglu_interleave(t)
+    assert g[:32, 0].tolist() == list(range(0, 32)) and g[32:64, 0].tolist() == list(range(64, 96))
+    assert g[64:96, 0].tolist() == list(range(32, 64)) and g[96:, 0].tolist() == list(range(96, 128))
+
+
+def test_scheduler_coefficients_equal_oracle_step():
+    from oracle.scheduler import DDIMScheduler as OracleDDIM
+    from stable_diffusion_videos_amd.scheduler import DDIMScheduler
+    for ptype in ("epsilon", "v_prediction"):
+        for eta in (0.0, 0.7):
+            o, s = OracleDDIM(prediction_type=ptype), DDIMScheduler(prediction_type=ptype)
+            o.set_timesteps(20)
+            s.set_timesteps(20)
+            assert o.timesteps.tolist() == s.timesteps.tolist()
+            tab = s.coefficient_table(eta)
+            assert tab.shape == (20, 4)
+            x, e, z = torch.randn(64), torch.randn(64), torch.randn(64)
+            for i, t in enumerate(o.timesteps):
+                ref = o.step(e, t, x, eta=eta, variance_noise=z)
+                got = tab[i, 0] * x + tab[i, 1] * e + tab[i, 2] * z
+                assert torch.allclose(got, ref, atol=2e-5, rtol=1e-5), (ptype, eta, i)
+    with pytest.raises(ValueError):
+        DDIMScheduler().set_timesteps(0)
+
+
+def test_partition_frames_covers_every_frame_once():
+    from stable_diffusion_videos_amd.parallel import partition_frames
+    for counts, skips in (([60], None), ([80, 80, 80], None), ([12, 6, 18], [3, 0, 17]), ([3, 3], None), ([1], None)):
+        for ws in (1, 2, 3, 4, 8):
+            seen = []
+            sizes = []
+            for r in range(ws):
+                share = partition_frames(counts, ws, r, skips)
+                n = 0
+                for clip, a, b in share:
+                    assert 0 <= a < b <= counts[clip]
+                    seen += [(clip, k) for k in range(a, b)]
+                    n += b - a
+                sizes.append(n)
+            sk = skips or [0] * len(counts)
+            expect = [(i, k) for i, c in enumerate(counts) for k in range(sk[i], c)]
+            assert seen == expect                  # contiguous, ordered, disjoint, complete
+            assert max(sizes) - min(sizes) <= 1    # balanced
+
+
+def test_hash_tokenizer_call_shape():
+    from stable_diffusion_videos_amd import config
+    from stable_diffusion_videos_amd.text import HashTokenizer
+    tok = HashTokenizer(config.sd14_text())
+    assert tok.model_max_length == 77
+    ids = tok(["a cat", "a " + "very " * 100 + "long prompt"], padding="max_length", max_length=77, truncation=True,
+              return_tensors="pt").input_ids
+    assert ids.shape == (2, 77) and ids.dtype == torch.long
+    assert ids[0, 0] == 49406 and ids[0, 3] == 49407 and ids[1, -1] == 49407
+    assert torch.equal(tok("a cat", max_length=77, truncation=True).input_ids[0], ids[0])
+    assert tok("a cat").input_ids[0, 1] == tok("A CAT").input_ids[0, 1]
+    long = tok("x " * 100).input_ids                      # no truncation -> longer than 77, as the reference handles at :299
+    assert long.shape[1] > 77
+
+
+def test_pipeline_surface_matches_reference_signature():
+    """Same public methods and keyword names as the reference class."""
+    import inspect
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline as P
+    walk = list(inspect.signature(P.walk).parameters)
+    assert walk == ["self", "prompts", "seeds", "num_interpolation_steps", "output_dir", "name", "image_file_ext", "fps",
+                    "num_inference_steps", "guidance_scale", "eta", "height", "width", "upsample", "batch_size", "resume",
+                    "audio_filepath", "audio_start_sec", "margin", "smooth", "negative_prompt", "make_video"]
+    call = list(inspect.signature(P.__call__).parameters)
+    assert call[:16] == ["self", "prompt", "height", "width", "num_inference_steps", "guidance_scale", "negative_prompt",
+                         "num_images_per_prompt", "eta", "generator", "latents", "output_type", "return_dict", "callback",
+                         "callback_steps", "text_embeddings"]
+    mcf = list(inspect.signature(P.make_clip_frames).parameters)
+    assert mcf[:19] == ["self", "prompt_a", "prompt_b", "seed_a", "seed_b", "num_interpolation_steps", "save_path",
+                        "num_inference_steps", "guidance_scale", "eta", "height", "width", "upsample", "batch_size",
+                        "image_file_ext", "T", "skip", "negative_prompt", "step"]
+    assert inspect.signature(P.walk).parameters["num_interpolation_steps"].default == 5
+    assert inspect.signature(P.walk).parameters["make_video"].default is True
+    for m in ("from_pretrained", "to", "enable_attention_slicing", "disable_attention_slicing", "generate_inputs",
+              "embed_text", "init_noise"):
+        assert hasattr(P, m)
+    pipe = P.from_pretrained("tiny")
+    assert pipe.vae_scale_factor == 8 and pipe.unet.in_channels == 4 and pipe.unet.config.sample_size == 16
+    assert pipe.tokenizer.model_max_length == 77 and pipe.safety_checker is None and pipe.tiled is False
+    assert P.from_pretrained("tiny", tiled=True).tiled is True
+    e = pipe.embed_text("a cat")
+    assert e.shape == (1, 77, 64)
+    n1, n2 = pipe.init_noise(42, (1, 4, 8, 8)), pipe.init_noise(42, (1, 4, 8, 8))
+    assert torch.equal(n1, n2) and n1.shape == (1, 4, 8, 8)

@@ -1,0 +1,94 @@
+"""CPU tests of the oracle itself: pinned against the reference where the reference can be executed
+(slerp golden vectors), structural checks elsewhere (parameter counts, schedule known answers)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import interp, models, pipeline
+from oracle.scheduler import DDIMScheduler
+
+GOLDEN_FILES = ["slerp_seed42_1337_fp32", "slerp_seed7_8_fp16", "slerp_parallel_fp32", "slerp_antiparallel_fp32",
+                "slerp_numpy_fp64"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_FILES)
+def test_slerp_bit_exact_vs_reference_golden(name):
+    """tests/golden/*.npz hold outputs of the reference's own slerp (utils.py:42-66, AST-lifted)."""
+    d = np.load(GOLDEN / f"{name}.npz")
+    for t in d["ts"]:
+        gold = d[f"t{int(t * 100):03d}"]
+        got = interp.slerp_np(float(t), d["v0"], d["v1"])
+        assert got.dtype == gold.dtype and np.array_equal(got, gold), (name, t)
+    # torch entry form (utils.py:45-49, :63-64)
+    got = interp.slerp(0.5, torch.from_numpy(d["v0"]), torch.from_numpy(d["v1"]))
+    assert np.array_equal(got.numpy(), d["t050"])
+
+
+def test_slerp_known_answers_from_survey():
+    """SURVEY.md 8c known-answer vectors (seeds 42 / 1337, CPU generator, fp32)."""
+    v0, v1 = interp.init_noise(42, (1, 4, 64, 64)), interp.init_noise(1337, (1, 4, 64, 64))
+    assert np.allclose(v0.flatten()[:4].numpy(), [1.9269152879714966, 1.4872840642929077, 0.9007171988487244,
+                                                  -2.1055209636688232])
+    assert abs(float(v0.norm()) - 128.51612854) < 1e-3 and abs(float(v1.norm()) - 128.01329041) < 1e-3
+    mid = interp.slerp(0.5, v0, v1)
+    assert np.allclose(mid.flatten()[:4].numpy(), [1.4916281700, 1.0030324459, 0.3829366863, -2.1377933025], atol=1e-6)
+    assert torch.equal(interp.slerp(0.0, v0, v1), v0) and torch.equal(interp.slerp(1.0, v0, v1), v1)
+    with pytest.raises(TypeError):      # fact 5: the reference cannot slerp bf16
+        interp.slerp(0.5, v0.bfloat16(), v1.bfloat16())
+
+
+def test_generate_inputs_batching():
+    ea, eb = torch.randn(1, 77, 8), torch.randn(1, 77, 8)
+    la, lb = interp.init_noise(1, (1, 4, 8, 8)), interp.init_noise(2, (1, 4, 8, 8))
+    out = list(interp.generate_inputs(ea, eb, la, lb, np.linspace(0, 1, 5), 2))
+    assert [o[0] for o in out] == [0, 1, 2]
+    assert [o[1].shape[0] for o in out] == [2, 2, 1]
+    assert torch.equal(out[0][1][0], ea[0]) and torch.equal(out[2][1][0], eb[0])
+    assert torch.equal(out[0][2][0], la[0]) and torch.equal(out[2][2][0], lb[0])
+
+
+def test_parameter_counts_match_sd_checkpoints():
+    with torch.device("meta"):
+        assert models.count_params(models.UNet2DConditionModel(models.sd14_unet_config())) == 859_520_964
+        assert models.count_params(models.UNet2DConditionModel(models.sd21_unet_config())) == 865_910_724
+        assert models.count_params(models.AutoencoderKLDecoder(models.sd_vae_config())) == 49_490_199
+
+
+def test_ddim_schedule_known_answers():
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == list(range(981, 0, -20))
+    assert abs(float(s.alphas_cumprod[0]) - 0.99915) < 1e-6
+    assert abs(float(s.alphas_cumprod[999]) - 0.0046601) < 1e-5
+    # eta = 0, eps = 0: x_prev = sqrt(a_prev / a_t) x
+    x = torch.ones(4)
+    out = s.step(torch.zeros(4), 981, x)
+    assert torch.allclose(out, x * (s.alphas_cumprod[961] / s.alphas_cumprod[981]) ** 0.5)
+    # last step falls back to final_alpha_cumprod = alphas_cumprod[0] (set_alpha_to_one=False)
+    out = s.step(torch.zeros(4), 1, x)
+    assert torch.allclose(out, x * (s.alphas_cumprod[0] / s.alphas_cumprod[1]) ** 0.5)
+    # v-prediction identity: v = 0 -> eps = sqrt(1-a) x, x0 = sqrt(a) x
+    v = DDIMScheduler(prediction_type="v_prediction")
+    v.set_timesteps(50)
+    a_t, a_p = v.alphas_cumprod[981], v.alphas_cumprod[961]
+    out = v.step(torch.zeros(4), 981, x)
+    assert torch.allclose(out, (a_p ** 0.5 * a_t ** 0.5 + (1 - a_p) ** 0.5 * (1 - a_t) ** 0.5) * x)
+
+
+def test_tiny_oracle_end_to_end_runs():
+    """The oracle's full control flow on a tiny architecture: shapes, range, determinism."""
+    torch.manual_seed(0)
+    ucfg = models.UNetConfig(sample_size=8, block_out_channels=(32, 64, 64, 64), attention_head_dim=(1, 2, 2, 2),
+                             cross_attention_dim=32)
+    vcfg = models.VAEConfig(block_out_channels=(32, 32, 64, 64))
+    unet, vae = models.UNet2DConditionModel(ucfg).eval(), models.AutoencoderKLDecoder(vcfg).eval()
+    ea, eb, un = torch.randn(1, 77, 32), torch.randn(1, 77, 32), torch.randn(1, 77, 32)
+    frames = pipeline.make_clip_frames(unet, vae, DDIMScheduler(), ea, eb, un, 42, 1337, 3, 64, 64, batch_size=2,
+                                       num_inference_steps=3)
+    assert frames.shape == (3, 64, 64, 3) and frames.dtype == np.uint8
+    again = pipeline.make_clip_frames(unet, vae, DDIMScheduler(), ea, eb, un, 42, 1337, 3, 64, 64, batch_size=1,
+                                      num_inference_steps=3)
+    assert np.abs(frames.astype(int) - again.astype(int)).max() <= 1
+    with pytest.raises(ValueError, match="Unexpected T shape"):
+        pipeline.make_clip_frames(unet, vae, DDIMScheduler(), ea, eb, un, 1, 2, 4, 64, 64, T=np.linspace(0, 1, 3))
