@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py - interpolated frames/sec of the StableDiffusionWalkPipeline hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-size B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): interpolated frames/sec, 512x512, 50 DDIM steps.  Workload at N=1 = BASELINE config[1]:
+SD-v1-4 architecture, bf16, 2 prompts, walk of K*B interpolated frames (default 5 x 12 = 60), CFG 7.5, eta 0.
+A "step" is one pass of the hot path over one batch of B frames: lerp(text embeddings) + slerp(noise) for the
+batch -> 50 x (UNet on 2B samples + fused CFG/DDIM update), each a hipGraph replay -> VAE decode -> uint8 frames
+copied to the host.  Endpoint embeddings / endpoint noise are resident in HBM before the timed region; PNG
+encoding is outside `value` (reported separately as `png_frames_per_sec_per_core`).  Weights are seeded synthetic
+(no checkpoints offline) - the arithmetic is shape-identical.  With N > 1 every rank runs the same number of
+steps on its own frames (weak scaling, no data-path collective; the weights arrive by ONE RCCL broadcast).
+
+Extra objects in the JSON line:
+  roofline     whole hot path against the dense bf16 MFMA peak: achieved = 82.84 TFLOP/frame (SURVEY.md 8d,
+               algorithmic, padding not counted) x frames/s/GPU; plus `kernels`: per-kernel algorithmic
+               TFLOP/s and share of GPU time from a HIP-event-bracketed eager pass (one UNet forward + one VAE
+               decode of the same batch) run outside the timed region.
+  cpu_baseline the CPU oracle (PyTorch eager fp32 restatement of the reference path) timed on this host's cores
+               on a bounded sample - 1 CFG UNet forward (2 samples) + 1 VAE decode at full size - and
+               extrapolated to 50 steps.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+FLOP_PER_FRAME = {"sd14": 82.84e12, "sd21": 220.66e12}   # 2*(UNet MAC*2*50 + VAE MAC)
+MFMA_PEAK_TFLOPS = 2500.0                                 # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("SDV_BENCH_BATCH", "12")))
+    ap.add_argument("--arch", default="sd14", choices=["sd14", "sd21", "tiny"])
+    ap.add_argument("--size", type=int, default=0, help="image size (default: 512 for sd14, 768 for sd21)")
+    ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-pass", action="store_true")
+    return ap.parse_args()
+
+
+class EventProfiler:
+    """LAUNCH_HOOK that brackets every observed launch with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def __call__(self, kind, info, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((kind, info, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, info, s, e in self.records:
+            a = agg.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += info.get("flops", 0.0)
+            a["bytes"] += info.get("bytes", 0.0)
+        return agg
+
+
+def kernel_pass(pipe, embeds, noise, size, steps):
+    """One eager UNet forward + one VAE decode of the bench batch with every hot launch timed by HIP events."""
+    from stable_diffusion_videos_amd import hip
+    B = embeds.shape[0]
+    h = size // 8
+    uncond = pipe._uncond_embeddings(None, B)
+    ctx = torch.cat([uncond, embeds])
+    pipe._schedule(steps, 0.0)
+    pipe.unet.prepare_context(ctx)
+    pipe.unet.reserve(2 * B, h, h)
+    x2 = torch.zeros((2 * B * h * h, 4), dtype=torch.bfloat16, device=pipe.device)
+    lat = hip.nchw_to_nhwc(noise)
+    hip.latents_to_unet_input(lat, x2, True, lat.numel())
+    step = torch.zeros(1, dtype=torch.int32, device=pipe.device)
+    pipe.unet.forward(x2, 2 * B, h, h, step)          # warm
+    torch.cuda.synchronize()
+    prof_u, prof_v = EventProfiler(), EventProfiler()
+    hip.LAUNCH_HOOK = prof_u
+    t0 = time.perf_counter()
+    pipe.unet.forward(x2, 2 * B, h, h, step)
+    torch.cuda.synchronize()
+    t_unet = time.perf_counter() - t0
+    hip.LAUNCH_HOOK = prof_v
+    pipe.vae.decode(lat * 0.18215)
+    torch.cuda.synchronize()
+    hip.LAUNCH_HOOK = None
+    su, sv = prof_u.summary(), prof_v.summary()
+    out = {}
+    tot_u = sum(a["ms"] for a in su.values())
+    tot_v = sum(a["ms"] for a in sv.values())
+    for name, s, tot in (("unet", su, tot_u), ("vae", sv, tot_v)):
+        for kind, a in sorted(s.items(), key=lambda kv: -kv[1]["ms"]):
+            out[f"{name}.{kind}"] = {
+                "launches": a["launches"], "ms": round(a["ms"], 3), "share": round(a["ms"] / max(tot, 1e-9), 3),
+                "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1) if a["flops"] and a["ms"] > 0 else None,
+                "gbps": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["bytes"] and not a["flops"] and a["ms"] > 0 else None,
+                "avg_us": round(1e3 * a["ms"] / a["launches"], 2)}
+    out["unet_forward_event_ms"] = round(tot_u, 3)
+    out["unet_forward_wall_ms_eager"] = round(t_unet * 1e3, 3)
+    out["vae_decode_event_ms"] = round(tot_v, 3)
+    return out
+
+
+def cpu_baseline(pipe_cfgs, size, inference_steps):
+    """Time the CPU oracle (kind "port") on a bounded sample of the same workload."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from helpers import make_oracle_unet, make_oracle_vae
+    from stable_diffusion_videos_amd import weights
+    ucfg, vcfg = pipe_cfgs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    u = make_oracle_unet(ucfg, weights.synthetic_state_dict(weights.unet_shapes(ucfg), seed=0))
+    v = make_oracle_vae(vcfg, weights.synthetic_state_dict(weights.vae_decoder_shapes(vcfg), seed=1))
+    h = size // 8
+    x = torch.randn(2, 4, h, h)
+    ctx = torch.randn(2, 77, ucfg.cross_attention_dim)
+    with torch.no_grad():
+        u(x[:, :, :8, :8], torch.tensor(981), ctx)      # page in the weights
+        t0 = time.perf_counter()
+        u(x, torch.tensor(981), ctx)
+        t_unet = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        v.decode(x[:1])
+        t_vae = time.perf_counter() - t0
+    per_frame = inference_steps * t_unet + t_vae
+    return {"value": round(1.0 / per_frame, 6), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (PyTorch eager fp32 restatement): 1 CFG UNet forward (2 samples, {t_unet:.2f} s) + 1 VAE "
+                      f"decode ({t_vae:.2f} s) at {size}x{size}, extrapolated to {inference_steps} steps "
+                      f"({per_frame:.1f} s/frame)"}
+
+
+def main():
+    args = parse()
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline, parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    size = args.size or {"sd14": 512, "sd21": 768, "tiny": 128}[args.arch]
+    B = args.batch_size
+
+    pipe = StableDiffusionWalkPipeline.from_pretrained({"sd14": "CompVis/stable-diffusion-v1-4",
+                                                        "sd21": "stabilityai/stable-diffusion-2-1", "tiny": "tiny"}[args.arch],
+                                                       arch=args.arch)
+    cfgs_for_cpu = (pipe.unet.config, pipe.vae.config)
+    pipe.to(dev)                                           # weight relayout (+ RCCL broadcast when world > 1)
+
+    # the walk: 2 prompts, seeds 42/1337; rank r owns frames [r*K*B, (r+1)*K*B) of world*K*B
+    total_frames = world * (args.steps + args.warmup) * B
+    T_all = np.linspace(0.0, 1.0, total_frames)
+    my_T = T_all[rank * (args.steps + args.warmup) * B:(rank + 1) * (args.steps + args.warmup) * B]
+    h = size // 8
+    gen = pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), my_T, B)
+
+    def one_step():
+        _, embeds, noise = next(gen)
+        out = pipe(latents=noise, text_embeddings=embeds, height=size, width=size,
+                   num_inference_steps=args.inference_steps, guidance_scale=7.5, eta=0.0, output_type="numpy_u8")
+        return out["images"]                               # uint8 NHWC frames on the host
+
+    for _ in range(args.warmup):
+        last = one_step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = one_step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = world * args.steps * B
+    fps = frames / elapsed
+    flop_per_frame = FLOP_PER_FRAME.get(args.arch)
+    result = {
+        "metric": "interpolated frames/sec (512x512, 50 DDIM steps)" if args.arch == "sd14" and size == 512 and
+        args.inference_steps == 50 else f"interpolated frames/sec ({size}x{size}, {args.inference_steps} DDIM steps)",
+        "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random-init SD weights, hash-tokenised prompts)",
+        "config": {"workload": f"{args.arch} walk, 2 prompts, {frames} interpolated frames ({args.steps} steps x "
+                               f"{B} frames x {world} GPU), {size}x{size}, {args.inference_steps} DDIM steps, CFG 7.5",
+                   "batch_size": B, "frames": frames, "parallelism": f"frame-sharded dp{world}", "hipgraph": pipe.use_graphs},
+    }
+    if rank == 0:
+        if flop_per_frame and args.inference_steps == 50:
+            ach = fps / world * flop_per_frame / 1e12
+            result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                  "flop_per_frame": flop_per_frame}
+        else:
+            result["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": None, "traffic": None}
+        if not args.no_kernel_pass:
+            _, embeds, noise = next(pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), my_T[:B], B))
+            result["roofline"]["kernels"] = kernel_pass(pipe, embeds, noise, size, args.inference_steps)
+        # host-side PNG encode rate (outside `value`; the reference pays it serially at :553)
+        from PIL import Image
+        import io
+        img = Image.fromarray(last[0])
+        t1 = time.perf_counter()
+        for _ in range(3):
+            img.save(io.BytesIO(), format="PNG")
+        result["png_frames_per_sec_per_core"] = round(3 / (time.perf_counter() - t1), 2)
+        if world == 1 and not args.no_cpu_baseline and args.arch != "tiny":
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfgs_for_cpu, size, args.inference_steps)
+            except Exception as exc:  # the GPU number must still be reported
+                result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {exc!r}"}
+        print(json.dumps(result), flush=True)
+    parallel.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,8 +21,11 @@ OBJDIR = PKG / "lib" / "obj"
 LIB = LIBDIR / "libsdv_hip.so"
 ARCH = "gfx950"
 
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
-         "-Wno-unused-result", "-I", str(INCLUDE)]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", str(INCLUDE)]
+# fast-math only where it buys throughput (MFMA epilogues / softmax); the interpolation + scheduler kernels keep
+# IEEE division so that slerp(0) == v0 and slerp(1) == v1 hold exactly, as in the reference's numpy arithmetic.
+FAST_MATH = {"sdv_gemm.hip", "sdv_attention.hip", "sdv_norm.hip"}
+FAST_FLAGS = ["-ffast-math", "-fno-finite-math-only"]
 
 
 def hipcc() -> str:
@@ -46,7 +49,7 @@ def _compile(src: Path, force: bool) -> Path:
     if (not force and obj.exists() and obj.stat().st_mtime >= src.stat().st_mtime
             and obj.stat().st_mtime >= _newest_dep()):
         return obj
-    cmd = [hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    cmd = [hipcc(), *FLAGS, *(FAST_FLAGS if src.name in FAST_MATH else []), "-c", str(src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")

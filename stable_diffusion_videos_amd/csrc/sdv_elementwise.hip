@@ -67,18 +67,19 @@ __global__ __launch_bounds__(kThreads) void slerp_batch_kernel(const float* __re
                                                                float dot_threshold, float* __restrict__ out) {
     const int f = blockIdx.y;
     const float t = T[f];
-    // the reference computes these in the tensor dtype (fp32); the reductions here are fp64
-    const float dot = (float)(stats[0] / (sqrt(stats[1]) * sqrt(stats[2])));
+    // the reductions and the two coefficients are evaluated in fp64 (once per block), then rounded to the
+    // fp32 the reference computes in; sin(x)/sin(x) == 1 exactly, so slerp(0) == v0 and slerp(1) == v1 hold.
+    const double dot = stats[0] / (sqrt(stats[1]) * sqrt(stats[2]));
     float s0, s1;
-    if (fabsf(dot) > dot_threshold) {
+    if (fabs(dot) > (double)dot_threshold) {
         s0 = 1.0f - t;
         s1 = t;
     } else {
-        const float theta0 = acosf(dot);
-        const float sin0 = sinf(theta0);
-        const float theta_t = theta0 * t;
-        s0 = sinf(theta0 - theta_t) / sin0;
-        s1 = sinf(theta_t) / sin0;
+        const double theta0 = acos(dot);
+        const double sin0 = sin(theta0);
+        const double theta_t = theta0 * (double)t;
+        s0 = (float)(sin(theta0 - theta_t) / sin0);
+        s1 = (float)(sin(theta_t) / sin0);
     }
     const long long n = (long long)C * HW;
     float* o = out + (long long)f * n;

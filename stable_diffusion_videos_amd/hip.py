@@ -115,6 +115,17 @@ F32 = torch.float32
 
 _zero_pages = {}
 
+# Optional launch observer used by bench.py's roofline pass: called as hook(kind, info_dict, launch_fn).  The
+# hook must call launch_fn() itself (it may bracket it with HIP events).  None = no overhead.
+LAUNCH_HOOK = None
+
+
+def _launch(kind: str, info: dict, fn):
+    if LAUNCH_HOOK is None:
+        fn()
+    else:
+        LAUNCH_HOOK(kind, info, fn)
+
 
 def zero_page(device) -> torch.Tensor:
     key = str(device)
@@ -150,7 +161,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, Hin, Win, Hout, Wout, int(circular)
     a.epi, a.bias_mode, a.bias_step_stride = epi, (bias_mode if bias is not None else 0), bias_step_stride
     a.batch, a.tile, a.alpha = batch, tile, alpha
-    _check(lib.sdv_gemm_bf16(C.byref(a), _stream()), "sdv_gemm_bf16")
+    taps = 1 if mode == 0 else 9
+    _launch("gemm" if mode == 0 else "conv3x3",
+            dict(M=M, N=N, K=K * taps, batch=batch, flops=2.0 * M * N * K * taps * batch, mode=mode, epi=epi),
+            lambda: _check(lib.sdv_gemm_bf16(C.byref(a), _stream()), "sdv_gemm_bf16"))
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, residual=None, out=None,
@@ -202,9 +216,10 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Lq: int,
               Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0):
     lib = load()
-    _check(lib.sdv_attention_bf16(_ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off,
-                                  _ptr(vt, BF16, "Vt"), _ptr(out, BF16, "O"), B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo,
-                                  scale, _stream()), "sdv_attention_bf16")
+    qp, kp, vp, op = _ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off, _ptr(vt, BF16, "Vt"), _ptr(out, BF16, "O")
+    _launch("attention", dict(B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, flops=4.0 * B * H * Lq * Lk * dh),
+            lambda: _check(lib.sdv_attention_bf16(qp, kp, vp, op, B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, scale, _stream()),
+                           "sdv_attention_bf16"))
 
 
 def softmax_rows_(s: torch.Tensor, rows: int, cols: int, ld: int):
@@ -228,11 +243,15 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg:
         out = torch.empty((nimg * HW, C1 + C2), dtype=BF16, device=x.device)
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise SdvHipError("groupnorm: inputs must be contiguous")
-    _check(lib.sdv_groupnorm_stats(_ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), C1, C2, nimg, HW, groups, splits,
-                                   _ptr(partials), _stream()), "sdv_groupnorm_stats")
-    _check(lib.sdv_groupnorm_apply(_ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), C1, C2, nimg, HW, groups, splits,
-                                   _ptr(partials), _ptr(gamma, F32, "gamma"), _ptr(beta, F32, "beta"), eps,
-                                   int(silu), _ptr(out, BF16, "Y"), _stream()), "sdv_groupnorm_apply")
+    nbytes = 2.0 * nimg * HW * (C1 + C2)
+    xp, x2p, pp, op = _ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), _ptr(partials), _ptr(out, BF16, "Y")
+    gp, bp = _ptr(gamma, F32, "gamma"), _ptr(beta, F32, "beta")
+    _launch("gn_stats", dict(bytes=nbytes),
+            lambda: _check(lib.sdv_groupnorm_stats(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, _stream()),
+                           "sdv_groupnorm_stats"))
+    _launch("gn_apply", dict(bytes=2 * nbytes),
+            lambda: _check(lib.sdv_groupnorm_apply(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, gp, bp, eps, int(silu),
+                                                   op, _stream()), "sdv_groupnorm_apply"))
     return out
 
 
@@ -243,8 +262,9 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         raise SdvHipError("layernorm: input must be contiguous")
     if out is None:
         out = torch.empty_like(x)
-    _check(lib.sdv_layernorm_bf16(_ptr(x, BF16, "X"), _ptr(gamma, F32), _ptr(beta, F32), eps, rows, Cn,
-                                  _ptr(out, BF16), _stream()), "sdv_layernorm_bf16")
+    xp, gp, bp, op = _ptr(x, BF16, "X"), _ptr(gamma, F32), _ptr(beta, F32), _ptr(out, BF16)
+    _launch("layernorm", dict(bytes=4.0 * rows * Cn),
+            lambda: _check(lib.sdv_layernorm_bf16(xp, gp, bp, eps, rows, Cn, op, _stream()), "sdv_layernorm_bf16"))
     return out
 
 
@@ -257,8 +277,10 @@ def conv3x3_cin_small(x, w, bias, *, nimg, H, W, circular=False, out=None):
     Cout = w.shape[0]
     if out is None:
         out = torch.empty((nimg * H * W, Cout), dtype=BF16, device=x.device)
-    _check(lib.sdv_conv3x3_cin_small(_ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out, BF16), nimg, H,
-                                     W, Cin, Cout, int(circular), _stream()), "sdv_conv3x3_cin_small")
+    xp, wp, bp, op = _ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out, BF16)
+    _launch("conv_cin_small", dict(flops=18.0 * nimg * H * W * Cin * Cout, bytes=2.0 * nimg * H * W * (Cin + Cout)),
+            lambda: _check(lib.sdv_conv3x3_cin_small(xp, wp, bp, op, nimg, H, W, Cin, Cout, int(circular), _stream()),
+                           "sdv_conv3x3_cin_small"))
     return out
 
 
@@ -266,9 +288,10 @@ def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_
     lib = load()
     Cin = x.shape[1]
     Cout = w.shape[0]
-    _check(lib.sdv_conv3x3_cout_small(_ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out_f32, F32),
-                                      _ptr(out_u8, torch.uint8), nimg, H, W, Cin, Cout, out_mode, int(circular),
-                                      _stream()), "sdv_conv3x3_cout_small")
+    xp, wp, bp, fp, up = _ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out_f32, F32), _ptr(out_u8, torch.uint8)
+    _launch("conv_cout_small", dict(flops=18.0 * nimg * H * W * Cin * Cout, bytes=2.0 * nimg * H * W * Cin),
+            lambda: _check(lib.sdv_conv3x3_cout_small(xp, wp, bp, fp, up, nimg, H, W, Cin, Cout, out_mode, int(circular),
+                                                      _stream()), "sdv_conv3x3_cout_small"))
 
 
 def latent_affine(x, wpq, bias, in_scale, out, npix, Cn):

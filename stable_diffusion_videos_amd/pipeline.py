@@ -383,7 +383,7 @@ class StableDiffusionWalkPipeline:
                 callback(i, int(self.scheduler.timesteps[i]), hip.nhwc_to_nchw(ent["latents"]))
         if kwargs.get("return_latents", False):
             return hip.nhwc_to_nchw(ent["latents"])
-        want_float = output_type != "pil"
+        want_float = output_type not in ("pil", "numpy_u8")       # "numpy_u8": rounded uint8 NHWC array, no PIL objects
         u8, f32 = self.vae.decode(ent["latents"], want_float=want_float)                         # :432-435
         if want_float:
             image = f32.cpu().numpy()                                                             # :438

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import bf16_round, psnr, rel_l2
+from conftest import bf16_round, psnr, rel_l2, report
 from helpers import unet_pair, vae_pair
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +56,7 @@ def test_tiny_unet_forward(hip, dev, tiled):
     with torch.no_grad():
         ref = oracle(x, torch.tensor(501), ctx)
     p = psnr(got, ref)
-    print(f"tiny unet (tiled={tiled}) eps PSNR {p:.1f} dB, rel-L2 {rel_l2(got, ref):.2e}")
+    report(f"tiny unet (tiled={tiled}) eps PSNR {p:.1f} dB, rel-L2 {rel_l2(got, ref):.2e}")
     assert p >= 40.0
 
 
@@ -71,7 +71,7 @@ def test_sd14_unet_forward_small_latent(hip, dev):
     with torch.no_grad():
         ref = oracle(x, torch.tensor(981), ctx)
     p = psnr(got, ref)
-    print(f"SD-1.4 unet eps PSNR {p:.1f} dB, rel-L2 {rel_l2(got, ref):.2e}, |eps|max {float(ref.abs().max()):.3f}")
+    report(f"SD-1.4 unet eps PSNR {p:.1f} dB, rel-L2 {rel_l2(got, ref):.2e}, |eps|max {float(ref.abs().max()):.3f}")
     assert p >= 40.0
 
 
@@ -85,7 +85,7 @@ def test_sd21_unet_forward_small_latent(hip, dev):
     with torch.no_grad():
         ref = oracle(x, torch.tensor(981), ctx)
     p = psnr(got, ref)
-    print(f"SD-2.1 unet eps PSNR {p:.1f} dB")
+    report(f"SD-2.1 unet eps PSNR {p:.1f} dB")
     assert p >= 40.0
 
 
@@ -103,7 +103,7 @@ def test_vae_decode(hip, dev, arch):
     got = f32.cpu().numpy()
     p = psnr(torch.from_numpy(got), torch.from_numpy(ref), peak=1.0)
     d8 = np.abs(u8.cpu().numpy().astype(int) - numpy_to_uint8(ref).astype(int))
-    print(f"{arch} vae image PSNR {p:.1f} dB, uint8 max-abs {d8.max()}, mean-abs {d8.mean():.3f}, "
+    report(f"{arch} vae image PSNR {p:.1f} dB, uint8 max-abs {d8.max()}, mean-abs {d8.mean():.3f}, "
           f"dynamic range [{ref.min():.2f},{ref.max():.2f}] std {ref.std():.3f}")
     assert got.shape == ref.shape == (2, 64, 64, 3)
     assert p >= 35.0
@@ -144,14 +144,14 @@ def test_pipeline_call_matches_oracle(hip, dev):
         outs[graphs] = out
         p = psnr(torch.from_numpy(out), torch.from_numpy(ref), peak=1.0)
         d8 = np.abs((out * 255).round().astype(int) - ref8.astype(int))
-        print(f"pipeline (graphs={graphs}) frame PSNR {p:.1f} dB, uint8 max-abs {d8.max()} mean-abs {d8.mean():.3f}")
+        report(f"pipeline (graphs={graphs}) frame PSNR {p:.1f} dB, uint8 max-abs {d8.max()} mean-abs {d8.mean():.3f}")
         assert out.shape == (2, 64, 64, 3) and p >= 30.0
     assert np.array_equal(outs[True], outs[False]), "hipGraph replay must equal eager launches bit-for-bit"
     # latents after the loop (before the VAE), which is where chained-step error shows
     lat_ref = denoise_and_decode(o_unet, o_vae, OracleDDIM(), emb, uncond, lat, 10, 7.5, return_latents=True)
     lat_got = pipe(latents=lat, text_embeddings=emb, height=64, width=64, num_inference_steps=10, guidance_scale=7.5,
                    return_latents=True).cpu()
-    print(f"latents after 10 steps: PSNR {psnr(lat_got, lat_ref):.1f} dB")
+    report(f"latents after 10 steps: PSNR {psnr(lat_got, lat_ref):.1f} dB")
     assert psnr(lat_got, lat_ref) >= 35.0
     # PIL output type and no-CFG path
     ims = pipe(latents=lat[:1], text_embeddings=emb[:1], height=64, width=64, num_inference_steps=3, guidance_scale=1.0).images
