@@ -69,6 +69,25 @@ class EventProfiler:
         e.record()
         self.records.append((kind, info, s, e))
 
+    def by_shape(self):
+        """Per distinct launch shape: launches, total ms, algorithmic TFLOP/s - the optimisation work-list."""
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, info, s, e in self.records:
+            key = (kind,) + tuple((k, info[k]) for k in ("M", "N", "K", "batch", "mode", "epi", "B", "H", "Lq", "Lk", "dh")
+                                  if k in info)
+            a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += info.get("flops", 0.0)
+            a["bytes"] += info.get("bytes", 0.0)
+        rows = []
+        for key, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            rows.append({"kind": key[0], **dict(key[1:]), "launches": a["launches"], "ms": round(a["ms"], 4),
+                         "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1) if a["flops"] else None,
+                         "gbps": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["bytes"] else None})
+        return rows
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
@@ -108,6 +127,9 @@ def kernel_pass(pipe, embeds, noise, size, steps):
     torch.cuda.synchronize()
     hip.LAUNCH_HOOK = None
     su, sv = prof_u.summary(), prof_v.summary()
+    if os.environ.get("SDV_SHAPE_REPORT"):
+        with open(os.environ["SDV_SHAPE_REPORT"], "w") as f:
+            json.dump({"unet": prof_u.by_shape(), "vae": prof_v.by_shape()}, f, indent=1)
     out = {}
     tot_u = sum(a["ms"] for a in su.values())
     tot_v = sum(a["ms"] for a in sv.values())
@@ -130,7 +152,10 @@ def cpu_baseline(pipe_cfgs, size, inference_steps):
     from helpers import make_oracle_unet, make_oracle_vae
     from stable_diffusion_videos_amd import weights
     ucfg, vcfg = pipe_cfgs
-    cores = os.cpu_count() or 1
+    # PyTorch eager CPU kernels stop scaling (and regress badly) far below this host's 256 hardware threads:
+    # 256 threads measured 158 s for the UNet sample vs seconds on 8-32, so the port uses at most 32 threads
+    # and reports that count as `cores`.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("SDV_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(cores)
     u = make_oracle_unet(ucfg, weights.synthetic_state_dict(weights.unet_shapes(ucfg), seed=0))
     v = make_oracle_vae(vcfg, weights.synthetic_state_dict(weights.vae_decoder_shapes(vcfg), seed=1))

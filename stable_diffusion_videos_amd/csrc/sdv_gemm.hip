@@ -25,7 +25,7 @@ namespace {
 
 constexpr int kBK = 64;  // K tile (bf16 elements) = 128 bytes per row
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool CONV>
 __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -50,94 +50,108 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
     const int n0 = bn * BN;
     const long long bz = blockIdx.z;
 
-    const uint16_t* __restrict__ X = p.X + bz * p.sX;
-    const uint16_t* __restrict__ X2 = p.X2;
-    const uint16_t* __restrict__ W = p.W + bz * p.sW;
-    const int mode = p.mode;
+    const uintptr_t Xb = (uintptr_t)(p.X + bz * p.sX);
+    const uintptr_t X2b = (uintptr_t)p.X2;
+    const uintptr_t Zb = (uintptr_t)p.zero_page;
     const int K = p.K;
 
-    // ---- per-lane staging bookkeeping -------------------------------------------------------
+    // ---- per-lane staging bookkeeping (branch-free: everything below is selects + adds) ---------
     const int rg = lane >> 3;  // row inside the 8-row group one wave-instruction moves
     const int pc = lane & 7;   // physical 16-B chunk inside the 128-B LDS row
-    long long xa[NX], xb[NX];
-    int xoy[NX], xox[NX], xlc[NX];
+    int xm[NX];                // dense: clamped row index; conv: pixel index of image origin
+    int xay[NX], xax[NX];      // conv: anchor coordinates (oy*stride, ox*stride) or (oy, ox) for upsample
+    int xlc[NX];               // byte offset of this lane's logical chunk inside a 128-B K tile
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int r = (wave + 4 * i) * 8 + rg;
         int m = m0 + r;
         m = m < p.M ? m : p.M - 1;
-        xlc[i] = (pc ^ ((r >> 1) & 7)) * 8;
-        if (mode == 0) {
-            xa[i] = (long long)m * p.ldx;
-            xb[i] = (long long)m * p.ldx2;
-            xoy[i] = 0;
-            xox[i] = 0;
-        } else {
+        xlc[i] = (pc ^ ((r >> 1) & 7)) * 16;
+        if constexpr (CONV) {
             const int hw = p.Hout * p.Wout;
             const int img = m / hw;
             const int rem = m - img * hw;
             const int oy = rem / p.Wout;
-            xa[i] = (long long)img * p.Hin * p.Win;
-            xb[i] = 0;
-            xoy[i] = oy;
-            xox[i] = rem - oy * p.Wout;
+            const int ox = rem - oy * p.Wout;
+            const int st = p.mode == 2 ? 2 : 1;
+            xm[i] = img * p.Hin * p.Win;
+            xay[i] = oy * st;
+            xax[i] = ox * st;
+        } else {
+            xm[i] = m;
+            xay[i] = 0;
+            xax[i] = 0;
         }
     }
-    long long wa[NW];
+    uintptr_t wp[NW];  // running source pointers of the W rows
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int r = (wave + 4 * (NX + i)) * 8 + rg;  // tile row (>= BM)
         int n = n0 + (r - BM);
         n = n < p.N ? n : p.N - 1;
-        wa[i] = (long long)n * p.ldw + (pc ^ ((r >> 1) & 7)) * 8;
+        wp[i] = (uintptr_t)(p.W + bz * p.sW) + ((long long)n * p.ldw) * 2 + (pc ^ ((r >> 1) & 7)) * 16;
     }
 
-    auto stage = [&](int buf, int tap, int kc) {
+    // The K loop walks segments = (tap, source) pairs; inside a segment every row pointer just advances by
+    // 128 B per tile (0 B for padding rows, which sit on the zero page).
+    uintptr_t xp[NX];
+    int xinc[NX];
+    int tap = 0, srcsel = 0, seg_left = 0;
+    const bool two_src = p.C1 < K;
+    const int up_shift = p.mode == 3 ? 1 : 0;
+    const int ext_y = p.mode == 3 ? p.Hout : p.Hin;  // extent the tap offset is applied in
+    const int ext_x = p.mode == 3 ? p.Wout : p.Win;
+
+    auto new_segment = [&]() {
+        const uintptr_t sbase = srcsel ? X2b : Xb;
+        const long long ld2 = 2LL * (srcsel ? p.ldx2 : p.ldx);
+        if constexpr (CONV) {
+            const int dy = tap / 3 - 1;
+            const int dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                int vy = xay[i] + dy, vx = xax[i] + dx;
+                if (p.circular) {
+                    vy = vy < 0 ? vy + ext_y : (vy >= ext_y ? vy - ext_y : vy);
+                    vx = vx < 0 ? vx + ext_x : (vx >= ext_x ? vx - ext_x : vx);
+                }
+                const int iy = vy >> up_shift, ix = vx >> up_shift;
+                const bool ok = ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win);
+                const long long pix = (long long)xm[i] + (long long)iy * p.Win + ix;
+                const uintptr_t a = sbase + (uintptr_t)(pix * ld2) + xlc[i];
+                xp[i] = ok ? a : Zb + xlc[i];
+                xinc[i] = ok ? 128 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                xp[i] = sbase + (uintptr_t)((long long)xm[i] * ld2) + xlc[i];
+                xinc[i] = 128;
+            }
+        }
+        seg_left = (srcsel ? K - p.C1 : p.C1) / kBK;
+    };
+
+    auto stage = [&](int buf) {
         char* base = smem + buf * TILE_BYTES;
-        const bool second = kc >= p.C1;
-        const uint16_t* src = second ? X2 : X;
-        const int ld = second ? p.ldx2 : p.ldx;
-        const int kcc = second ? kc - p.C1 : kc;
-        const int dy = tap / 3 - 1;
-        const int dx = tap - (tap / 3) * 3 - 1;
+        if (seg_left == 0) new_segment();
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const uint16_t* g;
-            if (mode == 0) {
-                g = src + (second ? xb[i] : xa[i]) + kcc + xlc[i];
-            } else {
-                int iy, ix;
-                bool ok = true;
-                if (mode == 3) {  // conv over the nearest-2x upsampled image (Hout = 2*Hin)
-                    int uy = xoy[i] + dy, ux = xox[i] + dx;
-                    if (p.circular) {
-                        uy = uy < 0 ? uy + p.Hout : (uy >= p.Hout ? uy - p.Hout : uy);
-                        ux = ux < 0 ? ux + p.Wout : (ux >= p.Wout ? ux - p.Wout : ux);
-                    } else {
-                        ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-                    }
-                    iy = uy >> 1;
-                    ix = ux >> 1;
-                } else {
-                    const int s = mode == 2 ? 2 : 1;
-                    iy = xoy[i] * s + dy;
-                    ix = xox[i] * s + dx;
-                    if (p.circular) {
-                        iy = iy < 0 ? iy + p.Hin : (iy >= p.Hin ? iy - p.Hin : iy);
-                        ix = ix < 0 ? ix + p.Win : (ix >= p.Win ? ix - p.Win : ix);
-                    } else {
-                        ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
-                    }
-                }
-                const long long pix = xa[i] + (long long)iy * p.Win + ix;
-                g = ok ? src + pix * ld + kcc + xlc[i] : p.zero_page + xlc[i];
-            }
-            glds16(g, base + (wave + 4 * i) * 1024);
+            glds16((const void*)xp[i], base + (wave + 4 * i) * 1024);
+            xp[i] += xinc[i];
         }
-        const long long kw = (long long)tap * K + kc;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            glds16(W + wa[i] + kw, base + (wave + 4 * (NX + i)) * 1024);
+            glds16((const void*)wp[i], base + (wave + 4 * (NX + i)) * 1024);
+            wp[i] += 128;
+        }
+        if (--seg_left == 0) {
+            if (two_src && srcsel == 0) {
+                srcsel = 1;
+            } else {
+                srcsel = 0;
+                ++tap;
+            }
         }
     };
 
@@ -177,19 +191,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
     };
 
     // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
-    const int ntaps = mode == 0 ? 1 : 9;
+    const int ntaps = CONV ? 9 : 1;
     const int nkt = (K / kBK) * ntaps;
-    int tap = 0, kc = 0;
-    stage(0, 0, 0);
+    stage(0);
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        kc += kBK;
-        if (kc == K) {
-            kc = 0;
-            ++tap;
-        }
-        if (kt + 1 < nkt) stage((kt + 1) & 1, tap, kc);
+        if (kt + 1 < nkt) stage((kt + 1) & 1);
         compute(kt & 1);
     }
 
@@ -283,20 +291,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
         }
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
+template <int WM, int WN, int TM, int TN, bool CONV>
+int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDS = 2 * (BM + BN) * 128;
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, CONV>), grid, dim3(256), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
+    return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, false>(a, stream) : launch_igemm_t<WM, WN, TM, TN, true>(a, stream);
 }
 
 }  // namespace
