@@ -26,6 +26,10 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 # IEEE division so that slerp(0) == v0 and slerp(1) == v1 hold exactly, as in the reference's numpy arithmetic.
 FAST_MATH = {"sdv_gemm.hip", "sdv_attention.hip", "sdv_norm.hip"}
 FAST_FLAGS = ["-ffast-math", "-fno-finite-math-only"]
+# attention: MFMA results are consumed by the softmax VALU code straight away - keep them in VGPRs (no
+# v_accvgpr_read/write traffic; 123+32 -> 128 registers, 3 -> 4 waves/SIMD for the 40/64-wide heads)
+EXTRA_FLAGS = {"sdv_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "sdv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc() -> str:
@@ -49,7 +53,7 @@ def _compile(src: Path, force: bool) -> Path:
     if (not force and obj.exists() and obj.stat().st_mtime >= src.stat().st_mtime
             and obj.stat().st_mtime >= _newest_dep()):
         return obj
-    cmd = [hipcc(), *FLAGS, *(FAST_FLAGS if src.name in FAST_MATH else []), "-c", str(src), "-o", str(obj)]
+    cmd = [hipcc(), *FLAGS, *(FAST_FLAGS if src.name in FAST_MATH else []), *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")

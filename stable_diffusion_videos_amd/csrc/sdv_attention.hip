@@ -19,6 +19,9 @@
 
 namespace {
 
+constexpr f32x16_t kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+constexpr float kDefer = 5.0f;  // log2 units: skip the O rescale while the running max moves by < 2^5
+
 template <int DH>
 struct AttnCfg {
     static constexpr int DKS = (DH + 15) / 16;        // 16-wide k-steps of Q.K^T
@@ -142,30 +145,44 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[j][e] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < DKS; ++ks) {
                 const bf16x8_t kf = *(const bf16x8_t*)(ldsK + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
-                s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
+                if (ks == 0)
+                    s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], kZero16, 0, 0, 0);   // C = inline 0
+                else
+                    s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
         }
-        // ---- online softmax (base-2), lane-local ----
+        // ---- online softmax (base-2), lane-local.  Raw scores stay unscaled; the softmax scale is folded into
+        //      the exp2 argument with one FMA.  Keys beyond Lk only exist in the last tile (uniform branch). ----
         const int kv0 = t * 64;
-        float mx = -INFINITY;
+        if (kv0 + 64 > Lk) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float v = s[j][r] * scale_log2e;
-                v = key < Lk ? v : -INFINITY;
-                s[j][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    s[j][r] = key < Lk ? s[j][r] : -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;      // scale > 0: max commutes with it
+        // deferred rescale: keep the old running max while the tile max grows by < kDefer (P stays <= 2^kDefer,
+        // exact in fp32 accumulation); when it fires, O and l are rescaled BEFORE this tile's P exists.
+        if (!__all(mx - m_run <= kDefer)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        }
         float psum = 0.f;
         bf16x8_t pf[4];
 #pragma unroll
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 float pv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    pv[e] = __builtin_amdgcn_exp2f(s[j][8 * u + e] - m_new);
+                    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][8 * u + e], scale_log2e, -m_run));
                     psum += pv[e];
                 }
                 u32x4_t pr;
@@ -185,11 +202,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 pr[3] = pack_bf16x2(pv[6], pv[7]);
                 pf[j * 2 + u] = __builtin_bit_cast(bf16x8_t, pr);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < DVT; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        l_run += psum;
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt)

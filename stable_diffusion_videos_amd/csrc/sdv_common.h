@@ -23,8 +23,12 @@ SDV_DEVICE uint16_t f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+// two fp32 -> packed bf16x2 with the gfx950 hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even)
 SDV_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
 SDV_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 SDV_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -26,14 +26,15 @@ namespace {
 constexpr int kBK = 64;  // K tile (bf16 elements) = 128 bytes per row
 
 template <int WM, int WN, int TM, int TN, bool CONV>
-__global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args p) {
+    constexpr int NWV = WM * WN;  // waves per workgroup (4 or 8)
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int ROWS = BM + BN;
     constexpr int TILE_BYTES = ROWS * 128;
-    constexpr int NX = BM / 32;  // X rows staged per lane per K tile
-    constexpr int NW = BN / 32;  // W rows staged per lane per K tile
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NX = BM / (8 * NWV);  // X rows staged per lane per K tile
+    constexpr int NW = BN / (8 * NWV);  // W rows staged per lane per K tile
+    static_assert(BM % (8 * NWV) == 0 && BN % (8 * NWV) == 0, "tile rows must split evenly over the waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -43,9 +44,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
     const int wm = wave / WN;
     const int wn = wave % WN;
 
+    // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs; remap
+    // (bijectively) so that each XCD - each private L2 - works on one contiguous run of tiles: neighbouring
+    // M tiles of a conv share their halo rows, and all tiles of a run share the same W panel.
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7;
+    const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int bm = blockIdx.x % tiles_m;
-    const int bn = blockIdx.x / tiles_m;
+    const int bm = tile_id % tiles_m;
+    const int bn = tile_id / tiles_m;
     const int m0 = bm * BM;
     const int n0 = bn * BN;
     const long long bz = blockIdx.z;
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
     int xlc[NX];               // byte offset of this lane's logical chunk inside a 128-B K tile
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const int r = (wave + 4 * i) * 8 + rg;
+        const int r = (wave + NWV * i) * 8 + rg;
         int m = m0 + r;
         m = m < p.M ? m : p.M - 1;
         xlc[i] = (pc ^ ((r >> 1) & 7)) * 16;
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
     uintptr_t wp[NW];  // running source pointers of the W rows
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const int r = (wave + 4 * (NX + i)) * 8 + rg;  // tile row (>= BM)
+        const int r = (wave + NWV * (NX + i)) * 8 + rg;  // tile row (>= BM)
         int n = n0 + (r - BM);
         n = n < p.N ? n : p.N - 1;
         wp[i] = (uintptr_t)(p.W + bz * p.sW) + ((long long)n * p.ldw) * 2 + (pc ^ ((r >> 1) & 7)) * 16;
@@ -137,12 +145,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sdv_gemm_args p) {
         if (seg_left == 0) new_segment();
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            glds16((const void*)xp[i], base + (wave + 4 * i) * 1024);
+            glds16((const void*)xp[i], base + (wave + NWV * i) * 1024);
             xp[i] += xinc[i];
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            glds16((const void*)wp[i], base + (wave + 4 * (NX + i)) * 1024);
+            glds16((const void*)wp[i], base + (wave + NWV * (NX + i)) * 1024);
             wp[i] += 128;
         }
         if (--seg_left == 0) {
@@ -302,7 +310,7 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, CONV>), grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, CONV>), grid, dim3(WM * WN * 64), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
 }
@@ -347,25 +355,35 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     if (a.alpha == 0.f) a.alpha = 1.f;
     hipStream_t s = (hipStream_t)stream;
     int tile = a.tile;
+    const long long nb = a.batch > 0 ? a.batch : 1;
+    auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nb; };
     if (tile == 0) {
-        // enough 128x128 tiles to cover the chip twice -> big tile; N not a multiple of 128 but of 64
-        // (e.g. 320 channels) -> 128x64 to avoid padded MFMA work; otherwise small tiles for occupancy.
-        const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
-        if (a.N % 128 != 0 && a.N % 64 == 0 && a.N <= 320)
+        // Largest tile that still yields about one workgroup per CU (256 CUs): the 8-wave 256-row tiles halve the
+        // L2->LDS operand traffic per MFMA of the 128x128 tile (whose ceiling is the L2 bandwidth), the small
+        // tiles keep the chip filled on the low-resolution levels.
+        const long long kFill = 224;
+        if (a.N % 320 == 0 && blocks(256, 320) >= kFill)
+            tile = 6;
+        else if (a.N % 256 == 0 && blocks(256, 256) >= kFill)
+            tile = 7;
+        else if (a.N % 128 == 0 && a.N <= 256 && blocks(256, 128) >= kFill)
+            tile = 8;
+        else if (a.N % 128 != 0 && a.N % 64 == 0 && a.N <= 320)
             tile = 2;
-        else if (big >= 256 || a.epi == 1)
+        else if (blocks(128, 128) >= kFill || a.epi == 1)
             tile = 1;
-        else {
-            const long long mid = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * (a.batch > 0 ? a.batch : 1);
-            tile = mid >= 256 ? 2 : 3;
-        }
+        else
+            tile = blocks(128, 64) >= kFill ? 2 : 3;
     }
     if (a.epi == 1 && tile == 3) tile = 2;
     switch (tile) {
-        case 1: return launch_igemm<2, 2, 2, 2>(a, s);
-        case 2: return launch_igemm<4, 1, 1, 2>(a, s);
-        case 3: return launch_igemm<2, 2, 1, 1>(a, s);
-        case 4: return launch_igemm<2, 2, 4, 2>(a, s);
+        case 1: return launch_igemm<2, 2, 2, 2>(a, s);   // 128 x 128, 4 waves
+        case 2: return launch_igemm<4, 1, 1, 2>(a, s);   // 128 x  64
+        case 3: return launch_igemm<2, 2, 1, 1>(a, s);   //  64 x  64
+        case 4: return launch_igemm<2, 2, 4, 2>(a, s);   // 256 x 128, 4 waves
+        case 6: return launch_igemm<4, 2, 2, 5>(a, s);   // 256 x 320, 8 waves (UNet widths are multiples of 320)
+        case 7: return launch_igemm<4, 2, 2, 4>(a, s);   // 256 x 256, 8 waves
+        case 8: return launch_igemm<4, 2, 2, 2>(a, s);   // 256 x 128, 8 waves
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
     return SDV_OK;

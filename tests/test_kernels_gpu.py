@@ -24,8 +24,12 @@ def rnd(shape, dev, seed, scale=1.0):
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 320, 320), (64, 77, 64), (1024, 640, 1280), (33, 130, 64)])
+ALL_TILES = [1, 2, 3, 4, 6, 7, 8]
+
+
+@pytest.mark.parametrize("tile", ALL_TILES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 320, 320), (64, 77, 64), (1024, 640, 1280), (33, 130, 64),
+                                   (1000, 960, 192)])
 def test_gemm_dense(hip, dev, tile, M, N, K):
     x, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, K ** -0.5)
     bias = rnd((N,), dev, 3)
@@ -42,13 +46,13 @@ def test_gemm_asymmetric_identity(hip, dev):
     n = 256
     x = torch.eye(n, device=dev)
     w = bf16_round(torch.arange(n * n, dtype=F32).reshape(n, n) % 251 - 125.0).to(dev)
-    for tile in (1, 2, 3, 4):
+    for tile in ALL_TILES:
         out = hip.linear(x.to(BF16), w.to(BF16), tile=tile)
         torch.cuda.synchronize()
         assert torch.equal(out.float(), w.T.contiguous()), f"tile {tile}"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 6, 7, 8])
 def test_gemm_epilogues(hip, dev, tile):
     M, N, K = 384, 256, 192
     x, w = rnd((M, K), dev, 5), rnd((N, K), dev, 6, K ** -0.5)
@@ -67,7 +71,7 @@ def test_gemm_epilogues(hip, dev, tile):
     assert rel_l2(out.float(), x @ w.T + bias_n) < MFMA_TOL
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 6, 7, 8])
 def test_gemm_geglu(hip, dev, tile):
     from stable_diffusion_videos_amd.weights import geglu_interleave
     M, Cc, K = 320, 128, 64          # proj: K -> 8*Cc... here value/gate halves of size 4*Cc = 512
@@ -118,16 +122,19 @@ def conv_ref(x_nhwc, w, bias, mode, circular):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize("tile", [0, 1, 6, 7])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("circular", [False, True])
-@pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320)])
-def test_conv3x3(hip, dev, mode, circular, n, H, W, Cin, Cout):
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320),
+                                            (2, 24, 24, 64, 640)])
+def test_conv3x3(hip, dev, tile, mode, circular, n, H, W, Cin, Cout):
     from stable_diffusion_videos_amd.weights import conv_w
     x = rnd((n, H, W, Cin), dev, 20)
     w = rnd((Cout, Cin, 3, 3), dev, 21, (9 * Cin) ** -0.5)
     bias = rnd((Cout,), dev, 22)
     ref = conv_ref(x, w, bias, mode, circular)
-    out = hip.conv3x3(x.reshape(-1, Cin).to(BF16), conv_w(w, dev), bias, nimg=n, H=H, W=W, mode=mode, circular=circular)
+    out = hip.conv3x3(x.reshape(-1, Cin).to(BF16), conv_w(w, dev), bias, nimg=n, H=H, W=W, mode=mode, circular=circular,
+                      tile=tile)
     torch.cuda.synchronize()
     assert out.shape[0] == ref.shape[0] * ref.shape[1] * ref.shape[2]
     assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL
@@ -143,9 +150,11 @@ def test_conv3x3_concat_residual_steptable(hip, dev):
     res = rnd((n, H, W, Cout), dev, 27)
     step = torch.tensor([3], dtype=torch.int32, device=dev)
     ref = conv_ref(torch.cat([x1, x2], -1), w, table[3], 1, False) + res
-    out = hip.conv3x3(x1.reshape(-1, C1).to(BF16), conv_w(w, dev), table, nimg=n, H=H, W=W, x2=x2.reshape(-1, C2).to(BF16),
-                      residual=res.reshape(-1, Cout).to(BF16), step_ptr=step, bias_step_stride=Cout)
-    assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL
+    for tile in (0, 1, 2, 3, 6, 7, 8):
+        out = hip.conv3x3(x1.reshape(-1, C1).to(BF16), conv_w(w, dev), table, nimg=n, H=H, W=W,
+                          x2=x2.reshape(-1, C2).to(BF16), residual=res.reshape(-1, Cout).to(BF16), step_ptr=step,
+                          bias_step_stride=Cout, tile=tile)
+        assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL, tile
 
 
 def test_conv_small_channel_kernels(hip, dev):
