@@ -19,6 +19,8 @@
 //     output channels n -> 8-byte bf16 stores / residual loads and per-register bias.
 //   * conv3x3: the K loop walks (tap, channel-tile); the per-lane source address is the shifted /
 //     strided / upsampled pixel, and padding pixels are redirected to a 256-B zero page in HBM.
+#include <type_traits>
+
 #include "sdv_common.h"
 
 namespace {
@@ -216,6 +218,105 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
     uint16_t* __restrict__ C = p.C + bz * p.sC;
     const uint16_t* __restrict__ R = p.R ? p.R + bz * p.sR : nullptr;
 
+    // ---- staged epilogue (the normal case): the wave parks its 32 x (TN*32) fp32 sub-tile in LDS, then writes /
+    //      reads HBM in whole rows - 16-byte coalesced stores and residual loads instead of the 8-byte,
+    //      32-lines-per-instruction pattern the MFMA C layout would give.  Per-wave private region, XOR-swizzled
+    //      16-byte chunks (conflict-free for both the b128 writes and the row reads). ----
+    {
+        const bool geglu = p.epi == 1;
+        const int ncols_out = geglu ? (p.N >> 1) : p.N;
+        const bool aligned = ((p.ldc & 7) == 0) && ((ncols_out & 7) == 0) && (!R || (p.ldr & 7) == 0) &&
+                             ((((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0) &&
+                             (((p.sC | p.sR) & 7) == 0) && (!geglu || (TN % 2 == 0));
+        if (aligned) {
+            constexpr int WCOLS = TN * 32;
+            float* stg = (float*)smem + wave * (32 * WCOLS);
+            __syncthreads();  // every wave has left the K loop: the tile buffers may be overwritten
+            const int wcol0 = n0 + wn * WCOLS;  // first (permuted, for GEGLU) weight row of this wave
+            auto drain = [&](auto oc_tag, int mt) {
+                constexpr int OC = decltype(oc_tag)::value;  // output columns of the wave per pass
+                constexpr int CPR = OC / 8;                  // 16-byte bf16 chunks per output row
+                const int ocol0 = geglu ? (wcol0 >> 1) : wcol0;
+#pragma unroll 2
+                for (int idx = lane; idx < 32 * CPR; idx += 64) {
+                    const int r = idx / CPR, cj = idx - r * CPR;
+                    const int m = m0 + wm * TM * 32 + mt * 32 + r;
+                    const int n = ocol0 + cj * 8;
+                    if (m < p.M && n < ncols_out) {
+                        const float4 a = *(const float4*)(stg + r * WCOLS + (((2 * cj) ^ (r & 7)) << 2));
+                        const float4 b = *(const float4*)(stg + r * WCOLS + (((2 * cj + 1) ^ (r & 7)) << 2));
+                        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        if (R) {
+                            const bf16x8_raw rr = *(const bf16x8_raw*)(R + (long long)m * p.ldr + n);
+                            float g[8];
+                            unpack8(rr, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        if (p.epi == 2) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+                        }
+                        *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
+                    }
+                }
+            };
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int mrow = m0 + wm * TM * 32 + mt * 32 + l31;
+                const float bm_ = (bias && p.bias_mode == 2 && mrow < p.M) ? bias[mrow] : 0.f;
+                if (geglu) {
+                    if constexpr (TN % 2 == 0) {
+#pragma unroll
+                        for (int nt = 0; nt < TN; nt += 2)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const int nv = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;
+                                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+                                if (bias && nv + 35 < p.N) {
+                                    bv = *(const float4*)(bias + nv);
+                                    bg = *(const float4*)(bias + nv + 32);
+                                }
+                                float4 o;
+                                o.x = (acc[nt][mt][4 * g4 + 0] * alpha + bv.x) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 0] * alpha + bg.x);
+                                o.y = (acc[nt][mt][4 * g4 + 1] * alpha + bv.y) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 1] * alpha + bg.y);
+                                o.z = (acc[nt][mt][4 * g4 + 2] * alpha + bv.z) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 2] * alpha + bg.z);
+                                o.w = (acc[nt][mt][4 * g4 + 3] * alpha + bv.w) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 3] * alpha + bg.w);
+                                const int chunk = (nt >> 1) * 8 + 2 * g4 + lhi;
+                                *(float4*)(stg + l31 * WCOLS + ((chunk ^ (l31 & 7)) << 2)) = o;
+                            }
+                        drain(std::integral_constant<int, (TN / 2) * 32 + (TN < 2 ? 32 : 0)>{}, mt);
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int nb = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;
+                            float4 bv = make_float4(bm_, bm_, bm_, bm_);
+                            if (bias && p.bias_mode == 1 && nb + 3 < p.N) {
+                                const float4 t4 = *(const float4*)(bias + nb);
+                                bv.x += t4.x;
+                                bv.y += t4.y;
+                                bv.z += t4.z;
+                                bv.w += t4.w;
+                            }
+                            float4 o;
+                            o.x = acc[nt][mt][4 * g4 + 0] * alpha + bv.x;
+                            o.y = acc[nt][mt][4 * g4 + 1] * alpha + bv.y;
+                            o.z = acc[nt][mt][4 * g4 + 2] * alpha + bv.z;
+                            o.w = acc[nt][mt][4 * g4 + 3] * alpha + bv.w;
+                            const int chunk = nt * 8 + 2 * g4 + lhi;
+                            *(float4*)(stg + l31 * WCOLS + ((chunk ^ (l31 & 7)) << 2)) = o;
+                        }
+                    drain(std::integral_constant<int, WCOLS>{}, mt);
+                }
+            }
+            return;
+        }
+    }
+
+    // ---- fallback epilogue straight from the MFMA registers (odd leading dims / N, e.g. the 77-token V^T) ----
     if (p.epi == 1) {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows of the same channels
         if constexpr (TN % 2 == 0) {
             const int nout = p.N >> 1;
@@ -302,7 +403,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
 template <int WM, int WN, int TM, int TN, bool CONV>
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int STG = WM * WN * 32 * TN * 32 * 4;              // fp32 staging of the epilogue
+    constexpr int LDS = 2 * (BM + BN) * 128 > STG ? 2 * (BM + BN) * 128 : STG;
+    static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -362,7 +465,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         // L2->LDS operand traffic per MFMA of the 128x128 tile (whose ceiling is the L2 bandwidth), the small
         // tiles keep the chip filled on the low-resolution levels.
         const long long kFill = 224;
-        if (a.N % 320 == 0 && blocks(256, 320) >= kFill)
+        if (a.epi != 1 && a.N % 320 == 0 && blocks(256, 320) >= kFill)
             tile = 6;
         else if (a.N % 256 == 0 && blocks(256, 256) >= kFill)
             tile = 7;
@@ -376,6 +479,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
             tile = blocks(128, 64) >= kFill ? 2 : 3;
     }
     if (a.epi == 1 && tile == 3) tile = 2;
+    if (a.epi == 1 && tile == 6) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU pairs n-tiles: needs an even TN
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2>(a, s);   // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2>(a, s);   // 128 x  64
