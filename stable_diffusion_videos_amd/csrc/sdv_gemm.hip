@@ -461,25 +461,27 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     const long long nb = a.batch > 0 ? a.batch : 1;
     auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nb; };
     if (tile == 0) {
-        // Largest tile that still yields about one workgroup per CU (256 CUs): the 8-wave 256-row tiles halve the
-        // L2->LDS operand traffic per MFMA of the 128x128 tile (whose ceiling is the L2 bandwidth), the small
-        // tiles keep the chip filled on the low-resolution levels.
-        const long long kFill = 224;
-        if (a.epi != 1 && a.N % 320 == 0 && blocks(256, 320) >= kFill)
-            tile = 6;
-        else if (a.N % 256 == 0 && blocks(256, 256) >= kFill)
-            tile = 7;
-        else if (a.N % 128 == 0 && a.N <= 256 && blocks(256, 128) >= kFill)
-            tile = 8;
-        else if (a.N % 128 != 0 && a.N % 64 == 0 && a.N <= 320)
-            tile = 2;
-        else if (blocks(128, 128) >= kFill || a.epi == 1)
-            tile = 1;
-        else
-            tile = blocks(128, 64) >= kFill ? 2 : 3;
+        // Cost model over the compiled tiles: rounds of resident workgroups x work per round / relative MFMA
+        // efficiency of the tile shape.  Big 8-wave tiles move the fewest L2->LDS bytes per MFMA (the 128x128
+        // tile is L2-bandwidth bound near 0.9 PF/s) but quantise badly on the low-resolution levels.
+        struct Cand { int id, bm, bn, occ; float eff; };
+        static const Cand cands[] = {{6, 256, 320, 1, 1.00f}, {7, 256, 256, 1, 0.95f}, {9, 128, 320, 1, 0.80f},
+                                     {8, 256, 128, 1, 0.75f}, {1, 128, 128, 2, 0.60f}, {2, 128, 64, 3, 0.45f},
+                                     {3, 64, 64, 4, 0.30f}};
+        double best = 1e300;
+        for (const Cand& c : cands) {
+            if (a.epi == 1 && (c.id == 6 || c.id == 9 || c.id == 3)) continue;   // GEGLU pairs n-tiles: even TN only
+            const long long nblk = blocks(c.bm, c.bn);
+            const long long rounds = (nblk + 256LL * c.occ - 1) / (256LL * c.occ);
+            const double cost = (double)rounds * c.occ * c.bm * c.bn / c.eff;       // padded tiles are counted in nblk
+            if (cost < best) {
+                best = cost;
+                tile = c.id;
+            }
+        }
     }
     if (a.epi == 1 && tile == 3) tile = 2;
-    if (a.epi == 1 && tile == 6) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU pairs n-tiles: needs an even TN
+    if (a.epi == 1 && (tile == 6 || tile == 9)) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU pairs n-tiles: even TN only
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2>(a, s);   // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2>(a, s);   // 128 x  64
@@ -488,6 +490,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         case 6: return launch_igemm<4, 2, 2, 5>(a, s);   // 256 x 320, 8 waves (UNet widths are multiples of 320)
         case 7: return launch_igemm<4, 2, 2, 4>(a, s);   // 256 x 256, 8 waves
         case 8: return launch_igemm<4, 2, 2, 2>(a, s);   // 256 x 128, 8 waves
+        case 9: return launch_igemm<4, 2, 1, 5>(a, s);   // 128 x 320, 8 waves
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
     return SDV_OK;
