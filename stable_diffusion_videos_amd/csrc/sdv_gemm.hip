@@ -60,61 +60,77 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
     const int n0 = bn * BN;
     const long long bz = blockIdx.z;
 
-    const uintptr_t Xb = (uintptr_t)(p.X + bz * p.sX);
-    const uintptr_t X2b = (uintptr_t)p.X2;
-    const uintptr_t Zb = (uintptr_t)p.zero_page;
     const int K = p.K;
 
-    // ---- per-lane staging bookkeeping (branch-free: everything below is selects + adds) ---------
+    // ---- operand addressing: buffer descriptors + 32-bit lane offsets + scalar K offset -----------------
+    // Every operand row is fetched with `buffer_load_dwordx4 ... offen lds` (LDS-DMA).  The descriptor base is
+    // anchored at this workgroup's first row, so a 31-bit lane offset always reaches the window it touches;
+    // the K position travels in the scalar offset (no per-tile VALU address math at all), and padding pixels /
+    // rows beyond M or N use an offset past num_records: the hardware range check returns zeros for them.
+    constexpr unsigned kOOB = 0x80000000u;
+    constexpr int kRecords = 0x7ffffff0;
     const int rg = lane >> 3;  // row inside the 8-row group one wave-instruction moves
     const int pc = lane & 7;   // physical 16-B chunk inside the 128-B LDS row
-    int xm[NX];                // dense: clamped row index; conv: pixel index of image origin
+    long long xbase1, xbase2;  // element offsets of the window start in X / X2 (wave-uniform)
+    int pix0 = 0;
+    if constexpr (CONV) {
+        pix0 = (m0 / (p.Hout * p.Wout)) * p.Hin * p.Win;
+        xbase1 = (long long)pix0 * p.ldx;
+        xbase2 = (long long)pix0 * p.ldx2;
+    } else {
+        xbase1 = bz * p.sX + (long long)m0 * p.ldx;
+        xbase2 = (long long)m0 * p.ldx2;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + xbase1), 0, kRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X2 + xbase2), 0, kRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + bz * p.sW + (long long)n0 * p.ldw), 0, kRecords, 0x00020000);
+
+    int xr_[NX];               // dense: row inside the tile (or -1 beyond M); conv: pixel index of the image origin - pix0
     int xay[NX], xax[NX];      // conv: anchor coordinates (oy*stride, ox*stride) or (oy, ox) for upsample
     int xlc[NX];               // byte offset of this lane's logical chunk inside a 128-B K tile
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int r = (wave + NWV * i) * 8 + rg;
-        int m = m0 + r;
-        m = m < p.M ? m : p.M - 1;
+        const int m = m0 + r;
         xlc[i] = (pc ^ ((r >> 1) & 7)) * 16;
         if constexpr (CONV) {
             const int hw = p.Hout * p.Wout;
-            const int img = m / hw;
-            const int rem = m - img * hw;
+            const int mc = m < p.M ? m : p.M - 1;
+            const int img = mc / hw;
+            const int rem = mc - img * hw;
             const int oy = rem / p.Wout;
             const int ox = rem - oy * p.Wout;
             const int st = p.mode == 2 ? 2 : 1;
-            xm[i] = img * p.Hin * p.Win;
+            xr_[i] = m < p.M ? img * p.Hin * p.Win - pix0 : -1;
             xay[i] = oy * st;
             xax[i] = ox * st;
         } else {
-            xm[i] = m;
+            xr_[i] = m < p.M ? r : -1;
             xay[i] = 0;
             xax[i] = 0;
         }
     }
-    uintptr_t wp[NW];  // running source pointers of the W rows
+    unsigned wvo[NW];  // lane byte offsets of the W rows relative to rs_w
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int r = (wave + NWV * (NX + i)) * 8 + rg;  // tile row (>= BM)
-        int n = n0 + (r - BM);
-        n = n < p.N ? n : p.N - 1;
-        wp[i] = (uintptr_t)(p.W + bz * p.sW) + ((long long)n * p.ldw) * 2 + (pc ^ ((r >> 1) & 7)) * 16;
+        const int rw = r - BM;
+        wvo[i] = (n0 + rw < p.N) ? (unsigned)(rw * p.ldw * 2 + (pc ^ ((r >> 1) & 7)) * 16) : kOOB;
     }
 
-    // The K loop walks segments = (tap, source) pairs; inside a segment every row pointer just advances by
-    // 128 B per tile (0 B for padding rows, which sit on the zero page).
-    uintptr_t xp[NX];
-    int xinc[NX];
+    // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
+    unsigned xvo[NX];
     int tap = 0, srcsel = 0, seg_left = 0;
+    int kx = 0;   // scalar byte offset inside the current X source
+    int kwb = 0;  // scalar byte offset along the W rows (all taps and sources are contiguous in K)
     const bool two_src = p.C1 < K;
     const int up_shift = p.mode == 3 ? 1 : 0;
     const int ext_y = p.mode == 3 ? p.Hout : p.Hin;  // extent the tap offset is applied in
     const int ext_x = p.mode == 3 ? p.Wout : p.Win;
 
     auto new_segment = [&]() {
-        const uintptr_t sbase = srcsel ? X2b : Xb;
-        const long long ld2 = 2LL * (srcsel ? p.ldx2 : p.ldx);
+        const int ld2 = 2 * (srcsel ? p.ldx2 : p.ldx);
         if constexpr (CONV) {
             const int dy = tap / 3 - 1;
             const int dx = tap - (tap / 3) * 3 - 1;
@@ -126,35 +142,32 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
                     vx = vx < 0 ? vx + ext_x : (vx >= ext_x ? vx - ext_x : vx);
                 }
                 const int iy = vy >> up_shift, ix = vx >> up_shift;
-                const bool ok = ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win);
-                const long long pix = (long long)xm[i] + (long long)iy * p.Win + ix;
-                const uintptr_t a = sbase + (uintptr_t)(pix * ld2) + xlc[i];
-                xp[i] = ok ? a : Zb + xlc[i];
-                xinc[i] = ok ? 128 : 0;
+                const bool ok = ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win) & (xr_[i] >= 0);
+                const int pix = xr_[i] + iy * p.Win + ix;
+                xvo[i] = ok ? (unsigned)(pix * ld2 + xlc[i]) : kOOB;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                xp[i] = sbase + (uintptr_t)((long long)xm[i] * ld2) + xlc[i];
-                xinc[i] = 128;
-            }
+            for (int i = 0; i < NX; ++i) xvo[i] = xr_[i] >= 0 ? (unsigned)(xr_[i] * ld2 + xlc[i]) : kOOB;
         }
+        kx = 0;
         seg_left = (srcsel ? K - p.C1 : p.C1) / kBK;
     };
 
     auto stage = [&](int buf) {
         char* base = smem + buf * TILE_BYTES;
         if (seg_left == 0) new_segment();
+        const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            glds16((const void*)xp[i], base + (wave + NWV * i) * 1024);
-            xp[i] += xinc[i];
-        }
+        for (int i = 0; i < NX; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(base + (wave + NWV * i) * 1024),
+                                                     16, (int)xvo[i], kx, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            glds16((const void*)wp[i], base + (wave + NWV * (NX + i)) * 1024);
-            wp[i] += 128;
-        }
+        for (int i = 0; i < NW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (wave + NWV * (NX + i)) * 1024),
+                                                     16, (int)wvo[i], kwb, 0, 0);
+        kx += 128;
+        kwb += 128;
         if (--seg_left == 0) {
             if (two_src && srcsel == 0) {
                 srcsel = 1;
@@ -176,27 +189,50 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
     const int l31 = lane & 31;
     const int lhi = lane >> 5;
 
+    // LDS byte offsets of this lane's fragment rows (swizzle term folded per k-step below)
+    int xrow_off[TM], xrow_sw[TM], wrow_off[TN], wrow_sw[TN];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int r = wm * TM * 32 + mt * 32 + l31;
+        xrow_off[mt] = r * 128;
+        xrow_sw[mt] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int r = BM + wn * TN * 32 + nt * 32 + l31;
+        wrow_off[nt] = r * 128;
+        wrow_sw[nt] = (r >> 1) & 7;
+    }
+
+    // Software-pipelined K tile: the fragments of k-step ks+1 are read into a second register set while the
+    // MFMAs of k-step ks issue (1 ds_read_b128 slotted behind each MFMA), so the matrix pipe does not wait for
+    // LDS latency inside the tile.
     auto compute = [&](int buf) {
         const char* base = smem + buf * TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < kBK / 16; ++ks) {
-            bf16x8_t xf[TM], wf[TN];
+        bf16x8_t xf[2][TM], wf[2][TN];
+        auto load_frags = [&](int ks, bf16x8_t* xd, bf16x8_t* wd) {
             const int lc = ks * 2 + lhi;
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const int r = wm * TM * 32 + mt * 32 + l31;
-                xf[mt] = *(const bf16x8_t*)(base + r * 128 + ((lc ^ ((r >> 1) & 7)) << 4));
-            }
+            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
 #pragma unroll
-            for (int nt = 0; nt < TN; ++nt) {
-                const int r = BM + wn * TN * 32 + nt * 32 + l31;
-                wf[nt] = *(const bf16x8_t*)(base + r * 128 + ((lc ^ ((r >> 1) & 7)) << 4));
-            }
+            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+        };
+        load_frags(0, xf[0], wf[0]);
+#pragma unroll
+        for (int ks = 0; ks < kBK / 16; ++ks) {
+            if (ks + 1 < kBK / 16) load_frags(ks + 1, xf[(ks + 1) & 1], wf[(ks + 1) & 1]);
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], xf[ks & 1][mt], acc[nt][mt], 0, 0, 0);
+            if (ks + 1 < kBK / 16) {
+#pragma unroll
+                for (int i = 0; i < TM + TN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+            }
         }
     };
 
