@@ -500,16 +500,15 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         // Cost model over the compiled tiles: rounds of resident workgroups x work per round / relative MFMA
         // efficiency of the tile shape.  Big 8-wave tiles move the fewest L2->LDS bytes per MFMA (the 128x128
         // tile is L2-bandwidth bound near 0.9 PF/s) but quantise badly on the low-resolution levels.
-        struct Cand { int id, bm, bn, occ; float eff; };
-        static const Cand cands[] = {{6, 256, 320, 1, 1.00f}, {7, 256, 256, 1, 0.95f}, {9, 128, 320, 1, 0.80f},
-                                     {8, 256, 128, 1, 0.75f}, {1, 128, 128, 2, 0.60f}, {2, 128, 64, 3, 0.45f},
-                                     {3, 64, 64, 4, 0.30f}};
+        // rate = measured MFMA throughput per busy CU (TFLOP/s, tools/tile_sweep.py on MI355X, K >= 1280)
+        struct Cand { int id, bm, bn; float rate; };
+        static const Cand cands[] = {{6, 256, 320, 4.9f}, {7, 256, 256, 4.6f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.2f},
+                                     {1, 128, 128, 3.15f}, {2, 128, 64, 2.2f}, {3, 64, 64, 2.5f}};
         double best = 1e300;
         for (const Cand& c : cands) {
             if (a.epi == 1 && (c.id == 6 || c.id == 9 || c.id == 3)) continue;   // GEGLU pairs n-tiles: even TN only
-            const long long nblk = blocks(c.bm, c.bn);
-            const long long rounds = (nblk + 256LL * c.occ - 1) / (256LL * c.occ);
-            const double cost = (double)rounds * c.occ * c.bm * c.bn / c.eff;       // padded tiles are counted in nblk
+            const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups the busiest CU runs
+            const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {
                 best = cost;
                 tile = c.id;
