@@ -55,7 +55,7 @@ int sdv_abi_version(void);
  *           2: as 0, then SiLU
  * bias      fp32; bias_mode 1 = per n, 2 = per m.  If step_ptr != NULL the bias row used is
  *           bias + (*step_ptr) * bias_step_stride (per-denoise-step time-embedding bias table).
- * zero_page >= 256 bytes of zeros in HBM (source of the conv padding halo).
+ * zero_page unused since ABI v1 kernels zero-fill padding through the buffer-descriptor range check (may be NULL).
  * batch     blockIdx.z; element strides sX/sW/sC/sR (0 = shared).
  * ------------------------------------------------------------------------------------------ */
 typedef struct sdv_gemm_args {
@@ -73,7 +73,7 @@ typedef struct sdv_gemm_args {
     int32_t mode, Hin, Win, Hout, Wout, circular;
     int32_t epi, bias_mode, bias_step_stride;
     int32_t batch;
-    int32_t tile;    /* 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves) */
+    int32_t tile;    /* 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 128x320, 11 = 128x256 with 32-wide K tiles (2 workgroups / CU) */
     float alpha;
 } sdv_gemm_args;
 

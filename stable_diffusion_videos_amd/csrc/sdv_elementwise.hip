@@ -241,9 +241,9 @@ __global__ __launch_bounds__(kThreads) void conv3x3_cin_small_kernel(const uint1
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* wl = (float*)smem_raw;  // [9*CIN][Cout]
     constexpr int KK = 9 * CIN;
-    for (int i = threadIdx.x; i < KK * Cout; i += kThreads) {
-        const int co = i / KK, k = i - co * KK;
-        wl[k * Cout + co] = bf16_to_f32(Wt[i]);
+    for (int i = threadIdx.x; i < KK * Cout; i += kThreads) {   // contiguous (conflict-free) LDS writes
+        const int k = i / Cout, co = i - k * Cout;
+        wl[i] = bf16_to_f32(Wt[co * KK + k]);
     }
     __syncthreads();
     const int cgroups = Cout >> 3;                  // 8-channel groups per pixel
@@ -308,25 +308,31 @@ __global__ __launch_bounds__(kThreads) void conv3x3_cout_small_kernel(const uint
         float acc[COUT];
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-        for (int wk = lane; wk < nwork; wk += 64) {
-            const int tap = wk / cchunks, ch = wk - tap * cchunks;
-            int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-            if (circular) {
-                iy = (iy + H) % H;
-                ix = (ix + Wd) % Wd;
-            } else if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) {
-                continue;
-            }
-            const bf16x8_raw xr = *(const bf16x8_raw*)(X + (((long long)img * H + iy) * Wd + ix) * Cin + ch * 8);
-            float xf[8];
-            unpack8(xr, xf);
+        // 8 predicated slots per sweep so that all of a lane's 16-byte loads are in flight together
+        for (int wbase = 0; wbase < nwork; wbase += 512) {
 #pragma unroll
-            for (int o = 0; o < COUT; ++o) {
-                const bf16x8_raw wr = *(const bf16x8_raw*)(wl + (o * 9 + tap) * Cin + ch * 8);
-                float wf[8];
-                unpack8(wr, wf);
+            for (int it = 0; it < 8; ++it) {
+                const int wk = wbase + lane + it * 64;
+                if (wk >= nwork) continue;
+                const int tap = wk / cchunks, ch = wk - tap * cchunks;
+                int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                if (circular) {
+                    iy = (iy + H) % H;
+                    ix = (ix + Wd) % Wd;
+                } else if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) {
+                    continue;
+                }
+                const bf16x8_raw xr = *(const bf16x8_raw*)(X + (((long long)img * H + iy) * Wd + ix) * Cin + ch * 8);
+                float xf[8];
+                unpack8(xr, xf);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[o] += xf[e] * wf[e];
+                for (int o = 0; o < COUT; ++o) {
+                    const bf16x8_raw wr = *(const bf16x8_raw*)(wl + (o * 9 + tap) * Cin + ch * 8);
+                    float wf[8];
+                    unpack8(wr, wf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o] += xf[e] * wf[e];
+                }
             }
         }
 #pragma unroll
@@ -464,7 +470,7 @@ extern "C" int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W, const
     const size_t lds = (size_t)9 * Cin * Cout * sizeof(float);
     SDV_REQUIRE(lds <= 160 * 1024, "sdv_conv3x3_cin_small: weights do not fit LDS");
     const long long total = (long long)nimg * H * Wd * (Cout / 8);
-    const unsigned grid = grid_for(total, kThreads, 4096);
+    const unsigned grid = grid_for(total, kThreads, 256 * 3);   // ~3 resident workgroups per CU, weights staged once each
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 4) {
         static bool attr = false;

@@ -8,35 +8,44 @@
 //
 // Design (CDNA4):
 //   * C[m][n] = sum_k X[m][k] W[n][k].  Both operands are K-contiguous rows, so both are staged the
-//     same way: 64-wide K tiles (128 B per row) go HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA,
-//     no VGPR round trip), double buffered, ONE barrier per K tile, next tile in flight during MFMA.
-//   * LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied on the
-//     per-lane SOURCE address and again on the ds_read_b128: physical 16-B chunk = logical chunk ^
-//     ((row >> 1) & 7).  With 128-B rows two rows share a 256-B bank row, and this spreads any 16
-//     rows that are distinct mod 16 over all 16 slots -> conflict-free ds_read_b128 fragments.
+//     same way: BK-wide K tiles go HBM -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR
+//     round trip), double buffered, ONE barrier per K tile, next tile in flight during the MFMAs.
+//   * Addressing = buffer descriptor anchored at the workgroup's first row + a 32-bit lane offset + the K
+//     position in the SCALAR offset: no per-tile VALU address math.  conv padding pixels and rows beyond
+//     M / N use an offset past num_records, so the descriptor range check writes zeros for them.
+//   * LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied on the per-lane
+//     SOURCE offset and again on the ds_read_b128 (conflict-free fragment reads for 128-B and 64-B rows).
 //   * v_mfma_f32_32x32x16_bf16 with the WEIGHT rows as the A operand and the ACTIVATION rows as the
-//     B operand: lane l then owns output row m = l & 31 and, per accumulator quad, 4 CONSECUTIVE
-//     output channels n -> 8-byte bf16 stores / residual loads and per-register bias.
-//   * conv3x3: the K loop walks (tap, channel-tile); the per-lane source address is the shifted /
-//     strided / upsampled pixel, and padding pixels are redirected to a 256-B zero page in HBM.
+//     B operand: lane l owns output row m = l & 31 and, per accumulator quad, 4 consecutive channels.
+//   * conv3x3: the K loop walks (tap, source, channel-tile) segments; only segment changes touch VALU.
+//   * Epilogue: fp32 sub-tiles are parked in LDS in 64-column passes and written as whole 128-byte row
+//     segments (16-B coalesced stores, residual loads prefetched before the pass).
+//   * Tiles: 8-wave 256x320 / 256x256 / 128x320 (UNet widths are multiples of 320) with 64-wide K tiles and one
+//     workgroup per CU; 8-wave 128x320 / 128x256 with 32-wide K tiles and TWO workgroups per CU (their
+//     prologues / epilogues overlap each other's MFMA phases - the short-K projections); small 4-wave tiles for
+//     the low-resolution levels.  XCD-aware tile order.
 #include <type_traits>
 
 #include "sdv_common.h"
 
 namespace {
 
-constexpr int kBK = 64;  // K tile (bf16 elements) = 128 bytes per row
-
-template <int WM, int WN, int TM, int TN, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args p) {
-    constexpr int NWV = WM * WN;  // waves per workgroup (4 or 8)
+// waves per SIMD the register allocator must leave room for: the 32-wide-K tiles are meant to run two workgroups
+// per CU (16 waves -> 4 per SIMD -> <= 128 VGPRs)
+template <int WM, int WN, int TM, int TN, int BK, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) void igemm_kernel(const sdv_gemm_args p) {
+    constexpr int NWV = WM * WN;            // waves per workgroup (4 or 8)
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int ROWS = BM + BN;
-    constexpr int TILE_BYTES = ROWS * 128;
-    constexpr int NX = BM / (8 * NWV);  // X rows staged per lane per K tile
-    constexpr int NW = BN / (8 * NWV);  // W rows staged per lane per K tile
-    static_assert(BM % (8 * NWV) == 0 && BN % (8 * NWV) == 0, "tile rows must split evenly over the waves");
+    constexpr int ROWB = BK * 2;            // bytes per LDS row (128 or 64)
+    constexpr int CPRW = BK / 8;            // 16-byte chunks per row (8 or 4)
+    constexpr int RPI = 1024 / ROWB;        // rows one wave-instruction (1 KiB) moves (8 or 16)
+    constexpr int TILE_BYTES = (BM + BN) * ROWB;
+    constexpr int GX = BM / RPI, GW = BN / RPI;                    // 1-KiB row groups of the X / W panels
+    constexpr int NX = (GX + NWV - 1) / NWV, NW = (GW + NWV - 1) / NWV;
+    constexpr int KSTEPS = BK / 16;
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "panels must be whole 1-KiB groups");
+    static_assert(BK == 64 || BK == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -59,19 +68,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
     const int m0 = bm * BM;
     const int n0 = bn * BN;
     const long long bz = blockIdx.z;
-
     const int K = p.K;
 
     // ---- operand addressing: buffer descriptors + 32-bit lane offsets + scalar K offset -----------------
-    // Every operand row is fetched with `buffer_load_dwordx4 ... offen lds` (LDS-DMA).  The descriptor base is
-    // anchored at this workgroup's first row, so a 31-bit lane offset always reaches the window it touches;
-    // the K position travels in the scalar offset (no per-tile VALU address math at all), and padding pixels /
-    // rows beyond M or N use an offset past num_records: the hardware range check returns zeros for them.
     constexpr unsigned kOOB = 0x80000000u;
     constexpr int kRecords = 0x7ffffff0;
-    const int rg = lane >> 3;  // row inside the 8-row group one wave-instruction moves
-    const int pc = lane & 7;   // physical 16-B chunk inside the 128-B LDS row
-    long long xbase1, xbase2;  // element offsets of the window start in X / X2 (wave-uniform)
+    const int rg = lane / CPRW;   // row inside the group one wave-instruction moves
+    const int pc = lane % CPRW;   // physical 16-B chunk inside the LDS row
+    auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    long long xbase1, xbase2;     // element offsets of the window start in X / X2 (wave-uniform)
     int pix0 = 0;
     if constexpr (CONV) {
         pix0 = (m0 / (p.Hout * p.Wout)) * p.Hin * p.Win;
@@ -88,12 +93,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
 
     int xr_[NX];               // dense: row inside the tile (or -1 beyond M); conv: pixel index of the image origin - pix0
     int xay[NX], xax[NX];      // conv: anchor coordinates (oy*stride, ox*stride) or (oy, ox) for upsample
-    int xlc[NX];               // byte offset of this lane's logical chunk inside a 128-B K tile
+    int xlc[NX];               // byte offset of this lane's logical chunk inside a K tile
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const int r = (wave + NWV * i) * 8 + rg;
+        const int r = (wave + NWV * i) * RPI + rg;
         const int m = m0 + r;
-        xlc[i] = (pc ^ ((r >> 1) & 7)) * 16;
+        xlc[i] = (pc ^ swz(r)) * 16;
         if constexpr (CONV) {
             const int hw = p.Hout * p.Wout;
             const int mc = m < p.M ? m : p.M - 1;
@@ -114,9 +119,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
     unsigned wvo[NW];  // lane byte offsets of the W rows relative to rs_w
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const int r = (wave + NWV * (NX + i)) * 8 + rg;  // tile row (>= BM)
-        const int rw = r - BM;
-        wvo[i] = (n0 + rw < p.N) ? (unsigned)(rw * p.ldw * 2 + (pc ^ ((r >> 1) & 7)) * 16) : kOOB;
+        const int rw = (wave + NWV * i) * RPI + rg;  // row inside the W panel
+        wvo[i] = (n0 + rw < p.N) ? (unsigned)(rw * p.ldw * 2 + (pc ^ swz(BM + rw)) * 16) : kOOB;
     }
 
     // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
             for (int i = 0; i < NX; ++i) xvo[i] = xr_[i] >= 0 ? (unsigned)(xr_[i] * ld2 + xlc[i]) : kOOB;
         }
         kx = 0;
-        seg_left = (srcsel ? K - p.C1 : p.C1) / kBK;
+        seg_left = (srcsel ? K - p.C1 : p.C1) / BK;
     };
 
     auto stage = [&](int buf) {
@@ -159,15 +163,21 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
         if (seg_left == 0) new_segment();
         const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(base + (wave + NWV * i) * 1024),
-                                                     16, (int)xvo[i], kx, 0, 0);
+        for (int i = 0; i < NX; ++i) {
+            const int g = wave + NWV * i;
+            if (GX % NWV == 0 || g < GX)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(base + g * 1024), 16,
+                                                         (int)xvo[i], kx, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (wave + NWV * (NX + i)) * 1024),
-                                                     16, (int)wvo[i], kwb, 0, 0);
-        kx += 128;
-        kwb += 128;
+        for (int i = 0; i < NW; ++i) {
+            const int g = wave + NWV * i;
+            if (GW % NWV == 0 || g < GW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024),
+                                                         16, (int)wvo[i], kwb, 0, 0);
+        }
+        kx += ROWB;
+        kwb += ROWB;
         if (--seg_left == 0) {
             if (two_src && srcsel == 0) {
                 srcsel = 1;
@@ -194,21 +204,39 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
         const int r = wm * TM * 32 + mt * 32 + l31;
-        xrow_off[mt] = r * 128;
-        xrow_sw[mt] = (r >> 1) & 7;
+        xrow_off[mt] = r * ROWB;
+        xrow_sw[mt] = swz(r);
     }
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
         const int r = BM + wn * TN * 32 + nt * 32 + l31;
-        wrow_off[nt] = r * 128;
-        wrow_sw[nt] = (r >> 1) & 7;
+        wrow_off[nt] = r * ROWB;
+        wrow_sw[nt] = swz(r);
     }
 
     // Software-pipelined K tile: the fragments of k-step ks+1 are read into a second register set while the
-    // MFMAs of k-step ks issue (1 ds_read_b128 slotted behind each MFMA), so the matrix pipe does not wait for
-    // LDS latency inside the tile.
+    // MFMAs of k-step ks issue (1 ds_read_b128 slotted behind each MFMA).
+    constexpr bool kPipeFrags = TM * TN >= 8;   // big tiles: 1 workgroup / CU, hide LDS latency inside the wave
     auto compute = [&](int buf) {
         const char* base = smem + buf * TILE_BYTES;
+        if constexpr (!kPipeFrags) {
+            // small wave tiles run 2+ workgroups per CU: other waves cover the LDS latency, registers matter more
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                bf16x8_t xs[TM], ws[TN];
+                const int lc = ks * 2 + lhi;
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) xs[mt] = *(const bf16x8_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) ws[nt] = *(const bf16x8_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[nt], xs[mt], acc[nt][mt], 0, 0, 0);
+            }
+            return;
+        }
         bf16x8_t xf[2][TM], wf[2][TN];
         auto load_frags = [&](int ks, bf16x8_t* xd, bf16x8_t* wd) {
             const int lc = ks * 2 + lhi;
@@ -219,14 +247,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
         };
         load_frags(0, xf[0], wf[0]);
 #pragma unroll
-        for (int ks = 0; ks < kBK / 16; ++ks) {
-            if (ks + 1 < kBK / 16) load_frags(ks + 1, xf[(ks + 1) & 1], wf[(ks + 1) & 1]);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks + 1 < KSTEPS) load_frags(ks + 1, xf[(ks + 1) & 1], wf[(ks + 1) & 1]);
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], xf[ks & 1][mt], acc[nt][mt], 0, 0, 0);
-            if (ks + 1 < kBK / 16) {
+            if (ks + 1 < KSTEPS) {
 #pragma unroll
                 for (int i = 0; i < TM + TN; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
 
     // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
     const int ntaps = CONV ? 9 : 1;
-    const int nkt = (K / kBK) * ntaps;
+    const int nkt = (K / BK) * ntaps;
     stage(0);
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -253,81 +281,64 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
     if (bias && p.step_ptr) bias += (long long)(*p.step_ptr) * p.bias_step_stride;
     uint16_t* __restrict__ C = p.C + bz * p.sC;
     const uint16_t* __restrict__ R = p.R ? p.R + bz * p.sR : nullptr;
+    const bool geglu = p.epi == 1;
+    const int wcol0 = n0 + wn * TN * 32;  // first (permuted, for GEGLU) weight row of this wave
 
-    // ---- staged epilogue (the normal case): the wave parks its 32 x (TN*32) fp32 sub-tile in LDS, then writes /
-    //      reads HBM in whole rows - 16-byte coalesced stores and residual loads instead of the 8-byte,
-    //      32-lines-per-instruction pattern the MFMA C layout would give.  Per-wave private region, XOR-swizzled
-    //      16-byte chunks (conflict-free for both the b128 writes and the row reads). ----
+    // ---- staged epilogue (the normal case): per pass the wave parks 32 rows x 64 columns (two n-tiles) of fp32
+    //      in its private LDS slab (XOR-swizzled 16-B chunks: conflict-free b128 writes and row reads), then writes
+    //      whole 128-byte row segments; the residual rows of the pass are fetched BEFORE the LDS phase so their
+    //      latency hides behind it. ----
     {
-        const bool geglu = p.epi == 1;
         const int ncols_out = geglu ? (p.N >> 1) : p.N;
         const bool aligned = ((p.ldc & 7) == 0) && ((ncols_out & 7) == 0) && (!R || (p.ldr & 7) == 0) &&
                              ((((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0) &&
                              (((p.sC | p.sR) & 7) == 0) && (!geglu || (TN % 2 == 0));
         if (aligned) {
-            constexpr int WCOLS = TN * 32;
-            float* stg = (float*)smem + wave * (32 * WCOLS);
+            float* stg = (float*)smem + wave * (32 * 64);
             __syncthreads();  // every wave has left the K loop: the tile buffers may be overwritten
-            const int wcol0 = n0 + wn * WCOLS;  // first (permuted, for GEGLU) weight row of this wave
-            auto drain = [&](auto oc_tag, int mt) {
-                constexpr int OC = decltype(oc_tag)::value;  // output columns of the wave per pass
-                constexpr int CPR = OC / 8;                  // 16-byte bf16 chunks per output row
-                const int ocol0 = geglu ? (wcol0 >> 1) : wcol0;
-#pragma unroll 2
-                for (int idx = lane; idx < 32 * CPR; idx += 64) {
-                    const int r = idx / CPR, cj = idx - r * CPR;
-                    const int m = m0 + wm * TM * 32 + mt * 32 + r;
-                    const int n = ocol0 + cj * 8;
-                    if (m < p.M && n < ncols_out) {
-                        const float4 a = *(const float4*)(stg + r * WCOLS + (((2 * cj) ^ (r & 7)) << 2));
-                        const float4 b = *(const float4*)(stg + r * WCOLS + (((2 * cj + 1) ^ (r & 7)) << 2));
-                        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                        if (R) {
-                            const bf16x8_raw rr = *(const bf16x8_raw*)(R + (long long)m * p.ldr + n);
-                            float g[8];
-                            unpack8(rr, g);
+            // one pass: n-tiles [nt0, nt0+ntc) of m-tile mt -> OC output columns starting at ocol
+            auto pass = [&](auto oc_tag, int mt, int nt0, int ocol) {
+                constexpr int OC = decltype(oc_tag)::value;   // 64 or 32 output columns
+                constexpr int CPO = OC / 8;                   // 16-byte bf16 chunks per output row
+                constexpr int ITERS = 32 * CPO / 64;
+                const int mbase = m0 + wm * TM * 32 + mt * 32;
+                bf16x8_raw rres[ITERS];
+                if (R) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += g[e];
-                        }
-                        if (p.epi == 2) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
-                        }
-                        *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int idx = lane + it * 64;
+                        const int r = idx / CPO, cj = idx % CPO;
+                        const int m = mbase + r, n = ocol + cj * 8;
+                        if (m < p.M && n < ncols_out) rres[it] = *(const bf16x8_raw*)(R + (long long)m * p.ldr + n);
                     }
                 }
-            };
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const int mrow = m0 + wm * TM * 32 + mt * 32 + l31;
+                const int mrow = mbase + l31;
                 const float bm_ = (bias && p.bias_mode == 2 && mrow < p.M) ? bias[mrow] : 0.f;
                 if (geglu) {
                     if constexpr (TN % 2 == 0) {
 #pragma unroll
-                        for (int nt = 0; nt < TN; nt += 2)
-#pragma unroll
-                            for (int g4 = 0; g4 < 4; ++g4) {
-                                const int nv = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;
-                                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
-                                if (bias && nv + 35 < p.N) {
-                                    bv = *(const float4*)(bias + nv);
-                                    bg = *(const float4*)(bias + nv + 32);
-                                }
-                                float4 o;
-                                o.x = (acc[nt][mt][4 * g4 + 0] * alpha + bv.x) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 0] * alpha + bg.x);
-                                o.y = (acc[nt][mt][4 * g4 + 1] * alpha + bv.y) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 1] * alpha + bg.y);
-                                o.z = (acc[nt][mt][4 * g4 + 2] * alpha + bv.z) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 2] * alpha + bg.z);
-                                o.w = (acc[nt][mt][4 * g4 + 3] * alpha + bv.w) * gelu_erf_f(acc[nt + 1][mt][4 * g4 + 3] * alpha + bg.w);
-                                const int chunk = (nt >> 1) * 8 + 2 * g4 + lhi;
-                                *(float4*)(stg + l31 * WCOLS + ((chunk ^ (l31 & 7)) << 2)) = o;
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int nv = wcol0 + nt0 * 32 + 8 * g4 + 4 * lhi;
+                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+                            if (bias && nv + 35 < p.N) {
+                                bv = *(const float4*)(bias + nv);
+                                bg = *(const float4*)(bias + nv + 32);
                             }
-                        drain(std::integral_constant<int, (TN / 2) * 32 + (TN < 2 ? 32 : 0)>{}, mt);
+                            float4 o;
+                            o.x = (acc[nt0][mt][4 * g4 + 0] * alpha + bv.x) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 0] * alpha + bg.x);
+                            o.y = (acc[nt0][mt][4 * g4 + 1] * alpha + bv.y) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 1] * alpha + bg.y);
+                            o.z = (acc[nt0][mt][4 * g4 + 2] * alpha + bv.z) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 2] * alpha + bg.z);
+                            o.w = (acc[nt0][mt][4 * g4 + 3] * alpha + bv.w) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 3] * alpha + bg.w);
+                            const int chunk = 2 * g4 + lhi;
+                            *(float4*)(stg + l31 * 64 + ((chunk ^ (l31 & 7)) << 2)) = o;
+                        }
                     }
                 } else {
 #pragma unroll
-                    for (int nt = 0; nt < TN; ++nt)
+                    for (int j = 0; j < OC / 32; ++j)
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
+                            const int nt = nt0 + j;
                             const int nb = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;
                             float4 bv = make_float4(bm_, bm_, bm_, bm_);
                             if (bias && p.bias_mode == 1 && nb + 3 < p.N) {
@@ -342,10 +353,45 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
                             o.y = acc[nt][mt][4 * g4 + 1] * alpha + bv.y;
                             o.z = acc[nt][mt][4 * g4 + 2] * alpha + bv.z;
                             o.w = acc[nt][mt][4 * g4 + 3] * alpha + bv.w;
-                            const int chunk = nt * 8 + 2 * g4 + lhi;
-                            *(float4*)(stg + l31 * WCOLS + ((chunk ^ (l31 & 7)) << 2)) = o;
+                            const int chunk = j * 8 + 2 * g4 + lhi;
+                            *(float4*)(stg + l31 * 64 + ((chunk ^ (l31 & 7)) << 2)) = o;
                         }
-                    drain(std::integral_constant<int, WCOLS>{}, mt);
+                }
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int idx = lane + it * 64;
+                    const int r = idx / CPO, cj = idx % CPO;
+                    const int m = mbase + r, n = ocol + cj * 8;
+                    if (m < p.M && n < ncols_out) {
+                        const float4 a = *(const float4*)(stg + r * 64 + (((2 * cj) ^ (r & 7)) << 2));
+                        const float4 b = *(const float4*)(stg + r * 64 + (((2 * cj + 1) ^ (r & 7)) << 2));
+                        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        if (R) {
+                            float g[8];
+                            unpack8(rres[it], g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        if (p.epi == 2) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+                        }
+                        *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
+                    }
+                }
+            };
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                if (geglu) {
+                    if constexpr (TN % 2 == 0) {
+#pragma unroll
+                        for (int nt = 0; nt < TN; nt += 2)
+                            pass(std::integral_constant<int, 32>{}, mt, nt, (wcol0 >> 1) + (nt >> 1) * 32);
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt + 1 < TN; nt += 2) pass(std::integral_constant<int, 64>{}, mt, nt, wcol0 + nt * 32);
+                    if constexpr (TN % 2 == 1) pass(std::integral_constant<int, 32>{}, mt, TN - 1, wcol0 + (TN - 1) * 32);
                 }
             }
             return;
@@ -353,7 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
     }
 
     // ---- fallback epilogue straight from the MFMA registers (odd leading dims / N, e.g. the 77-token V^T) ----
-    if (p.epi == 1) {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows of the same channels
+    if (geglu) {
         if constexpr (TN % 2 == 0) {
             const int nout = p.N >> 1;
 #pragma unroll
@@ -364,8 +410,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
                     if (m >= p.M) continue;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const int nv = n0 + wn * TN * 32 + nt * 32 + 8 * g4 + 4 * lhi;  // value row (permuted index)
-                        const int oc = ((n0 + wn * TN * 32 + nt * 32) >> 1) + 8 * g4 + 4 * lhi;
+                        const int nv = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;  // value row (permuted index)
+                        const int oc = ((wcol0 + nt * 32) >> 1) + 8 * g4 + 4 * lhi;
                         if (oc >= nout) continue;
                         float v[4];
 #pragma unroll
@@ -398,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
             const float bm_ = (bias && p.bias_mode == 2) ? bias[m] : 0.f;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = n0 + wn * TN * 32 + nt * 32 + 8 * g4 + 4 * lhi;
+                const int nb = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;
                 if (nb >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -436,27 +482,30 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const sdv_gemm_args
         }
 }
 
-template <int WM, int WN, int TM, int TN, bool CONV>
+template <int WM, int WN, int TM, int TN, int BK, bool CONV>
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int STG = WM * WN * 32 * TN * 32 * 4;              // fp32 staging of the epilogue
-    constexpr int LDS = 2 * (BM + BN) * 128 > STG ? 2 * (BM + BN) * 128 : STG;
+    constexpr int TILES = 2 * (BM + BN) * BK * 2;
+    constexpr int STG = WM * WN * 32 * 64 * 4;                    // fp32 staging slabs of the epilogue
+    constexpr int LDS = TILES > STG ? TILES : STG;
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, BK, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS);
         attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, CONV>), grid, dim3(WM * WN * 64), LDS, stream, a);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV>), grid, dim3(WM * WN * 64), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BK>
 int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
-    return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, false>(a, stream) : launch_igemm_t<WM, WN, TM, TN, true>(a, stream);
+    return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false>(a, stream)
+                       : launch_igemm_t<WM, WN, TM, TN, BK, true>(a, stream);
 }
 
 }  // namespace
@@ -466,18 +515,16 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     sdv_gemm_args a = *args;
     SDV_REQUIRE(a.X && a.W && a.C, "sdv_gemm_bf16: null operand");
     SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
-    SDV_REQUIRE(a.K % kBK == 0, "sdv_gemm_bf16: K=%d must be a multiple of %d", a.K, kBK);
+    SDV_REQUIRE(a.K % 64 == 0, "sdv_gemm_bf16: K=%d must be a multiple of 64", a.K);
     SDV_REQUIRE(a.mode >= 0 && a.mode <= 3, "sdv_gemm_bf16: bad mode %d", a.mode);
     if (!a.X2) {
         a.C1 = a.K;
         a.ldx2 = a.ldx;
         a.X2 = a.X;
     }
-    SDV_REQUIRE(a.C1 % kBK == 0 && a.C1 > 0 && a.C1 <= a.K, "sdv_gemm_bf16: C1=%d must be a multiple of %d in (0,K]",
-                a.C1, kBK);
+    SDV_REQUIRE(a.C1 % 64 == 0 && a.C1 > 0 && a.C1 <= a.K, "sdv_gemm_bf16: C1=%d must be a multiple of 64 in (0,K]", a.C1);
     SDV_REQUIRE(a.ldx % 8 == 0 && a.ldx2 % 8 == 0 && a.ldw % 8 == 0, "sdv_gemm_bf16: ldx/ldx2/ldw must be multiples of 8");
     if (a.mode != 0) {
-        SDV_REQUIRE(a.zero_page != nullptr, "sdv_gemm_bf16: conv modes need zero_page");
         SDV_REQUIRE(a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "sdv_gemm_bf16: bad conv geometry");
         SDV_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "sdv_gemm_bf16: M must be nimg*Hout*Wout");
         SDV_REQUIRE(a.ldw >= 9 * a.K, "sdv_gemm_bf16: conv weights must be [N][3][3][K]");
@@ -485,7 +532,13 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         if (a.mode == 1) SDV_REQUIRE(a.Hin == a.Hout && a.Win == a.Wout, "conv s1 geometry");
         if (a.mode == 2) SDV_REQUIRE(a.Hout == (a.Hin + 1) / 2 && a.Wout == (a.Win + 1) / 2, "conv s2 geometry");
         if (a.mode == 3) SDV_REQUIRE(a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win, "upsample-conv geometry");
+        // 31-bit lane offsets inside the workgroup's window (a 320-row tile spans at most 320/HWout + 2 images)
+        const long long win = ((long long)(320 / (a.Hout * a.Wout)) + 2) * a.Hin * a.Win * (a.ldx > a.ldx2 ? a.ldx : a.ldx2) * 2;
+        SDV_REQUIRE(win < 0x7fffffffLL, "sdv_gemm_bf16: conv window too large for 31-bit offsets");
+    } else {
+        SDV_REQUIRE(320LL * (a.ldx > a.ldx2 ? a.ldx : a.ldx2) * 2 < 0x7fffffffLL, "sdv_gemm_bf16: ldx too large");
     }
+    SDV_REQUIRE(320LL * a.ldw * 2 < 0x7fffffffLL, "sdv_gemm_bf16: ldw too large");
     if (a.epi == 1) {
         SDV_REQUIRE(a.N % 64 == 0, "sdv_gemm_bf16: GEGLU needs N %% 64 == 0");
         SDV_REQUIRE(a.ldc % 4 == 0, "sdv_gemm_bf16: GEGLU needs ldc %% 4 == 0");
@@ -496,19 +549,23 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     int tile = a.tile;
     const long long nb = a.batch > 0 ? a.batch : 1;
     auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nb; };
+    const long long ktiles = (long long)(a.K / 64) * (a.mode == 0 ? 1 : 9);
     if (tile == 0) {
-        // Cost model over the compiled tiles: rounds of resident workgroups x work per round / relative MFMA
-        // efficiency of the tile shape.  Big 8-wave tiles move the fewest L2->LDS bytes per MFMA (the 128x128
-        // tile is L2-bandwidth bound near 0.9 PF/s) but quantise badly on the low-resolution levels.
-        // rate = measured MFMA throughput per busy CU (TFLOP/s, tools/tile_sweep.py on MI355X, K >= 1280)
-        struct Cand { int id, bm, bn; float rate; };
-        static const Cand cands[] = {{6, 256, 320, 4.9f}, {7, 256, 256, 4.6f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.2f},
-                                     {1, 128, 128, 3.15f}, {2, 128, 64, 2.2f}, {3, 64, 64, 2.5f}};
+        // Cost model over the compiled tiles (tools/tile_sweep.py, tools/gemm_overhead.py on MI355X):
+        //   per-CU time = workgroups the busiest CU runs x (fixed prologue/epilogue cost + K tiles x tile work / rate).
+        // `rate` = MFMA throughput per busy CU in the K loop, `fixed` = un-overlapped per-workgroup latency expressed in
+        // the same units; tiles that fit two workgroups per CU (occ 2) overlap the fixed part with the other one's loop.
+        struct Cand { int id, bm, bn, occ; float rate, fixed; };
+        static const Cand cands[] = {{6, 256, 320, 1, 4.9f, 5.0f},  {7, 256, 256, 1, 4.6f, 5.0f},  {9, 128, 320, 1, 4.2f, 5.0f},
+                                     {10, 128, 320, 2, 4.4f, 1.5f}, {11, 128, 256, 2, 4.2f, 1.5f}, {8, 256, 128, 1, 3.2f, 4.0f},
+                                     {1, 128, 128, 2, 3.15f, 1.5f}, {2, 128, 64, 3, 2.2f, 1.0f},   {3, 64, 64, 4, 2.5f, 0.7f}};
         double best = 1e300;
         for (const Cand& c : cands) {
-            if (a.epi == 1 && (c.id == 6 || c.id == 9 || c.id == 3)) continue;   // GEGLU pairs n-tiles: even TN only
-            const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups the busiest CU runs
-            const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
+            if (a.epi == 1 && (c.id == 6 || c.id == 9 || c.id == 10 || c.id == 3)) continue;   // GEGLU pairs n-tiles: even TN
+            const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;                          // workgroups on the busiest CU
+            const double loop = (double)ktiles * c.bm * c.bn / c.rate;                          // K-loop time of one workgroup
+            const double fix = c.fixed * 256.0 * 320.0 / 4.9;                                   // in K-tile units of tile 6
+            const double cost = per_cu * loop + (per_cu + c.occ - 1) / c.occ * fix;
             if (cost < best) {
                 best = cost;
                 tile = c.id;
@@ -516,16 +573,18 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         }
     }
     if (a.epi == 1 && tile == 3) tile = 2;
-    if (a.epi == 1 && (tile == 6 || tile == 9)) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU pairs n-tiles: even TN only
+    if (a.epi == 1 && (tile == 6 || tile == 9 || tile == 10)) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU: even TN only
     switch (tile) {
-        case 1: return launch_igemm<2, 2, 2, 2>(a, s);   // 128 x 128, 4 waves
-        case 2: return launch_igemm<4, 1, 1, 2>(a, s);   // 128 x  64
-        case 3: return launch_igemm<2, 2, 1, 1>(a, s);   //  64 x  64
-        case 4: return launch_igemm<2, 2, 4, 2>(a, s);   // 256 x 128, 4 waves
-        case 6: return launch_igemm<4, 2, 2, 5>(a, s);   // 256 x 320, 8 waves (UNet widths are multiples of 320)
-        case 7: return launch_igemm<4, 2, 2, 4>(a, s);   // 256 x 256, 8 waves
-        case 8: return launch_igemm<4, 2, 2, 2>(a, s);   // 256 x 128, 8 waves
-        case 9: return launch_igemm<4, 2, 1, 5>(a, s);   // 128 x 320, 8 waves
+        case 1: return launch_igemm<2, 2, 2, 2, 64>(a, s);    // 128 x 128, 4 waves
+        case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
+        case 3: return launch_igemm<2, 2, 1, 1, 64>(a, s);    //  64 x  64
+        case 4: return launch_igemm<2, 2, 4, 2, 64>(a, s);    // 256 x 128, 4 waves
+        case 6: return launch_igemm<4, 2, 2, 5, 64>(a, s);    // 256 x 320, 8 waves (UNet widths are multiples of 320)
+        case 7: return launch_igemm<4, 2, 2, 4, 64>(a, s);    // 256 x 256, 8 waves
+        case 8: return launch_igemm<4, 2, 2, 2, 64>(a, s);    // 256 x 128, 8 waves
+        case 9: return launch_igemm<4, 2, 1, 5, 64>(a, s);    // 128 x 320, 8 waves
+        case 10: return launch_igemm<4, 2, 1, 5, 32>(a, s);   // 128 x 320, 8 waves, 32-wide K tiles: 2 workgroups / CU
+        case 11: return launch_igemm<4, 2, 1, 4, 32>(a, s);   // 128 x 256, 8 waves, 32-wide K tiles: 2 workgroups / CU
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
     return SDV_OK;
