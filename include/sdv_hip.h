@@ -73,7 +73,7 @@ typedef struct sdv_gemm_args {
     int32_t mode, Hin, Win, Hout, Wout, circular;
     int32_t epi, bias_mode, bias_step_stride;
     int32_t batch;
-    int32_t tile;    /* 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 128x320, 11 = 128x256 with 32-wide K tiles (2 workgroups / CU) */
+    int32_t tile;    /* 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves) */
     float alpha;
 } sdv_gemm_args;
 

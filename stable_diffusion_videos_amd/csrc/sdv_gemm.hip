@@ -20,10 +20,8 @@
 //   * conv3x3: the K loop walks (tap, source, channel-tile) segments; only segment changes touch VALU.
 //   * Epilogue: fp32 sub-tiles are parked in LDS in 64-column passes and written as whole 128-byte row
 //     segments (16-B coalesced stores, residual loads prefetched before the pass).
-//   * Tiles: 8-wave 256x320 / 256x256 / 128x320 (UNet widths are multiples of 320) with 64-wide K tiles and one
-//     workgroup per CU; 8-wave 128x320 / 128x256 with 32-wide K tiles and TWO workgroups per CU (their
-//     prologues / epilogues overlap each other's MFMA phases - the short-K projections); small 4-wave tiles for
-//     the low-resolution levels.  XCD-aware tile order.
+//   * Tiles: 8-wave 256x320 / 256x256 / 128x320 (UNet widths are multiples of 320), one workgroup per CU; small
+//     4-wave tiles for the low-resolution levels; chosen per launch by a measured cost model.  XCD-aware order.
 #include <type_traits>
 
 #include "sdv_common.h"
@@ -549,23 +547,21 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     int tile = a.tile;
     const long long nb = a.batch > 0 ? a.batch : 1;
     auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nb; };
-    const long long ktiles = (long long)(a.K / 64) * (a.mode == 0 ? 1 : 9);
     if (tile == 0) {
-        // Cost model over the compiled tiles (tools/tile_sweep.py, tools/gemm_overhead.py on MI355X):
-        //   per-CU time = workgroups the busiest CU runs x (fixed prologue/epilogue cost + K tiles x tile work / rate).
-        // `rate` = MFMA throughput per busy CU in the K loop, `fixed` = un-overlapped per-workgroup latency expressed in
-        // the same units; tiles that fit two workgroups per CU (occ 2) overlap the fixed part with the other one's loop.
-        struct Cand { int id, bm, bn, occ; float rate, fixed; };
-        static const Cand cands[] = {{6, 256, 320, 1, 4.9f, 5.0f},  {7, 256, 256, 1, 4.6f, 5.0f},  {9, 128, 320, 1, 4.2f, 5.0f},
-                                     {10, 128, 320, 2, 4.4f, 1.5f}, {11, 128, 256, 2, 4.2f, 1.5f}, {8, 256, 128, 1, 3.2f, 4.0f},
-                                     {1, 128, 128, 2, 3.15f, 1.5f}, {2, 128, 64, 3, 2.2f, 1.0f},   {3, 64, 64, 4, 2.5f, 0.7f}};
+        // Cost model over the compiled tiles, calibrated with tools/tile_sweep.py on MI355X: time ~ workgroups the
+        // busiest CU runs x tile area / rate, rate = MFMA throughput per busy CU (TFLOP/s) of that tile's K loop.
+        // The 8-wave 256-row tiles move the fewest L2->LDS bytes per MFMA (the 128x128 tile saturates L2 bandwidth
+        // near 0.9 PF/s) but quantise badly on the low-resolution levels, where the small tiles win.
+        // (Measured and rejected: 32-wide K tiles with two workgroups per CU - slower than one big workgroup on
+        //  every UNet shape, short K included; profiles/round1_tile_sweep_nimg64.txt.)
+        struct Cand { int id, bm, bn; float rate; };
+        static const Cand cands[] = {{6, 256, 320, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
+                                     {1, 128, 128, 3.4f}, {2, 128, 64, 2.4f}, {3, 64, 64, 2.0f}};
         double best = 1e300;
         for (const Cand& c : cands) {
-            if (a.epi == 1 && (c.id == 6 || c.id == 9 || c.id == 10 || c.id == 3)) continue;   // GEGLU pairs n-tiles: even TN
-            const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;                          // workgroups on the busiest CU
-            const double loop = (double)ktiles * c.bm * c.bn / c.rate;                          // K-loop time of one workgroup
-            const double fix = c.fixed * 256.0 * 320.0 / 4.9;                                   // in K-tile units of tile 6
-            const double cost = per_cu * loop + (per_cu + c.occ - 1) / c.occ * fix;
+            if (a.epi == 1 && (c.id == 6 || c.id == 9 || c.id == 3)) continue;   // GEGLU pairs n-tiles: even TN only
+            const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
+            const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {
                 best = cost;
                 tile = c.id;
@@ -573,7 +569,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         }
     }
     if (a.epi == 1 && tile == 3) tile = 2;
-    if (a.epi == 1 && (tile == 6 || tile == 9 || tile == 10)) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU: even TN only
+    if (a.epi == 1 && (tile == 6 || tile == 9)) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU pairs n-tiles: even TN only
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2, 64>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
@@ -583,8 +579,6 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         case 7: return launch_igemm<4, 2, 2, 4, 64>(a, s);    // 256 x 256, 8 waves
         case 8: return launch_igemm<4, 2, 2, 2, 64>(a, s);    // 256 x 128, 8 waves
         case 9: return launch_igemm<4, 2, 1, 5, 64>(a, s);    // 128 x 320, 8 waves
-        case 10: return launch_igemm<4, 2, 1, 5, 32>(a, s);   // 128 x 320, 8 waves, 32-wide K tiles: 2 workgroups / CU
-        case 11: return launch_igemm<4, 2, 1, 4, 32>(a, s);   // 128 x 256, 8 waves, 32-wide K tiles: 2 workgroups / CU
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
     return SDV_OK;

@@ -122,7 +122,9 @@ class StableDiffusionWalkPipeline:
         if model_dir is not None:
             ucfg = cfgs.unet_from_json(model_dir / "unet" / "config.json")
             vcfg = cfgs.vae_from_json(model_dir / "vae" / "config.json")
-            tcfg = cfgs.sd21_text() if ucfg.cross_attention_dim == 1024 else cfgs.sd14_text()
+            tcfg = {1024: cfgs.sd21_text(), 768: cfgs.sd14_text()}.get(ucfg.cross_attention_dim) or cfgs.TextConfig(
+                hidden_size=ucfg.cross_attention_dim, intermediate_size=4 * ucfg.cross_attention_dim, num_hidden_layers=2,
+                num_attention_heads=max(1, ucfg.cross_attention_dim // 64))
             u_sd = weights.load_component(model_dir, "unet", weights.unet_shapes(ucfg))
             v_sd = weights.load_component(model_dir, "vae", weights.vae_decoder_shapes(vcfg))
         else:

@@ -182,3 +182,36 @@ def test_pipeline_surface_matches_reference_signature():
     assert e.shape == (1, 77, 64)
     n1, n2 = pipe.init_noise(42, (1, 4, 8, 8)), pipe.init_noise(42, (1, 4, 8, 8))
     assert torch.equal(n1, n2) and n1.shape == (1, 4, 8, 8)
+
+
+def test_local_checkpoint_directory_round_trip(tmp_path):
+    """from_pretrained(<diffusers-layout dir>) reads config.json + safetensors with the diffusers key schema
+    (old VAE attention names included) - the path real SD weights take."""
+    import json
+    from safetensors.torch import save_file
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline, config, weights
+    ucfg, vcfg = config.tiny_unet(), config.tiny_vae()
+    u_sd = weights.synthetic_state_dict(weights.unet_shapes(ucfg), seed=11)
+    v_sd = weights.synthetic_state_dict(weights.vae_decoder_shapes(vcfg), seed=12)
+    (tmp_path / "unet").mkdir()
+    (tmp_path / "vae").mkdir()
+    (tmp_path / "unet" / "config.json").write_text(json.dumps(
+        dict(sample_size=ucfg.sample_size, block_out_channels=list(ucfg.block_out_channels),
+             attention_head_dim=list(ucfg.attention_head_dim), cross_attention_dim=ucfg.cross_attention_dim,
+             _class_name="UNet2DConditionModel", act_fn="silu")))
+    (tmp_path / "vae" / "config.json").write_text(json.dumps(
+        dict(block_out_channels=list(vcfg.block_out_channels), latent_channels=4, _class_name="AutoencoderKL")))
+    save_file({k: v.half() for k, v in u_sd.items()}, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    old = {k.replace(".to_q.", ".query.").replace(".to_k.", ".key.").replace(".to_v.", ".value.")
+           .replace(".to_out.0.", ".proj_attn."): v for k, v in v_sd.items()}
+    old["encoder.conv_in.weight"] = torch.zeros(1)          # extra (encoder) keys are ignored
+    save_file(old, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    pipe = StableDiffusionWalkPipeline.from_pretrained(str(tmp_path))
+    assert pipe.unet.config.block_out_channels == tuple(ucfg.block_out_channels)
+    assert pipe.unet.config.attention_head_dim == tuple(ucfg.attention_head_dim)
+    for k, v in u_sd.items():
+        assert torch.allclose(pipe.unet.state_dict[k], v.half().float()), k
+    for k, v in v_sd.items():
+        assert torch.equal(pipe.vae.state_dict[k], v), k
+    with pytest.raises(FileNotFoundError):
+        weights.load_component(tmp_path, "text_encoder", {})

@@ -242,3 +242,54 @@ def test_call_argument_errors(hip, dev):
     pipe(text_embeddings=emb, height=64, width=64, num_inference_steps=4, callback=lambda i, t, l: seen.append((i, t, tuple(l.shape))),
          callback_steps=2)
     assert seen == [(0, 751, (1, 4, 8, 8)), (2, 251, (1, 4, 8, 8))]
+
+
+def test_sd14_full_size_two_steps(hip, dev):
+    """BASELINE config geometry - SD-v1-4 architecture at 512x512 (64x64 latent, 4096-token attention), CFG 7.5 -
+    for one frame and 2 DDIM steps, against the CPU oracle (~15 s of oracle time)."""
+    from oracle.pipeline import denoise_and_decode, numpy_to_uint8
+    from oracle.scheduler import DDIMScheduler as OracleDDIM
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline
+    pipe = StableDiffusionWalkPipeline.from_pretrained("CompVis/stable-diffusion-v1-4", arch="sd14")
+    o_unet, o_vae = _oracle_for((pipe.unet, pipe.vae))
+    pipe.to(dev)
+    emb = pipe.embed_text("a cat").cpu()
+    uncond = pipe.embed_text("").cpu()
+    lat = pipe.init_noise(42, (1, 4, 64, 64)).cpu()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = denoise_and_decode(o_unet, o_vae, OracleDDIM(), emb, uncond, lat, num_inference_steps=2, guidance_scale=7.5)
+    out = pipe(latents=lat, text_embeddings=emb, num_inference_steps=2, guidance_scale=7.5, output_type="numpy")["images"]
+    p = psnr(torch.from_numpy(out), torch.from_numpy(ref), peak=1.0)
+    d8 = np.abs((out * 255).round().astype(int) - numpy_to_uint8(ref).astype(int))
+    report(f"SD-1.4 512x512, 2 steps, CFG: frame PSNR {p:.1f} dB, uint8 max-abs {d8.max()} mean-abs {d8.mean():.3f}")
+    assert out.shape == (1, 512, 512, 3) and p >= 30.0
+
+
+def test_pipeline_variants(hip, dev):
+    """eta > 0 (DDIM variance noise), negative prompt, num_images_per_prompt, prompt= entry, v-prediction."""
+    from oracle.pipeline import denoise_and_decode
+    from oracle.scheduler import DDIMScheduler as OracleDDIM
+    from stable_diffusion_videos_amd import DDIMScheduler, StableDiffusionWalkPipeline
+    for ptype in ("epsilon", "v_prediction"):
+        pipe = StableDiffusionWalkPipeline.from_pretrained("tiny", scheduler=DDIMScheduler(prediction_type=ptype))
+        o_unet, o_vae = _oracle_for((pipe.unet, pipe.vae))
+        pipe.to(dev)
+        emb = pipe.embed_text("a cat").cpu()
+        neg = pipe.embed_text("blurry").cpu()
+        lat = pipe.init_noise(7, (1, 4, 8, 8)).cpu()
+        steps = 6
+        g = torch.Generator().manual_seed(3)
+        out = pipe(latents=lat, text_embeddings=emb, height=64, width=64, num_inference_steps=steps, guidance_scale=5.0,
+                   eta=0.5, negative_prompt="blurry", generator=g, output_type="numpy")["images"]
+        # the pipeline draws (steps, B, h, w, C) NHWC variance noise from the generator; mirror it for the oracle
+        noise = torch.randn((steps, 1, 8, 8, 4), generator=torch.Generator().manual_seed(3)).permute(0, 1, 4, 2, 3)
+        ref = denoise_and_decode(o_unet, o_vae, OracleDDIM(prediction_type=ptype), emb, neg, lat, steps, 5.0, eta=0.5,
+                                 variance_noise=list(noise))
+        p = psnr(torch.from_numpy(out), torch.from_numpy(ref), peak=1.0)
+        report(f"tiny pipeline {ptype} eta=0.5 negative prompt: frame PSNR {p:.1f} dB")
+        assert p >= 30.0
+    ims = pipe(prompt=["a cat", "a dog"], height=64, width=64, num_inference_steps=2, num_images_per_prompt=2,
+               generator=torch.Generator().manual_seed(0)).images
+    assert len(ims) == 4
+    with pytest.raises(ValueError, match="negative_prompt"):
+        pipe(prompt=["a cat", "a dog"], negative_prompt=["x"], height=64, width=64, num_inference_steps=1)

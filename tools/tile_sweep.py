@@ -9,8 +9,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stable_diffusion_videos_amd import hip  # noqa: E402
 
-TILES = {1: "128x128", 2: "128x64", 3: "64x64", 6: "256x320", 7: "256x256", 8: "256x128", 9: "128x320",
-         10: "128x320k32", 11: "128x256k32"}
+TILES = {1: "128x128", 2: "128x64", 3: "64x64", 6: "256x320", 7: "256x256", 8: "256x128", 9: "128x320"}
 
 
 def bench(fn, reps=5):
