@@ -119,20 +119,25 @@ class _Transformer:
         hip.gemm(self.wv2, ctx, ent[1], M=C, N=Lc, K=D, ldx=D, ldw=D, ldc=ldv, batch=nimg, sX=0, sW=Lc * D,
                  sC=C * ldv)
 
-    def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor):
+    def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False):
+        """x: [nimg*HW, C] tokens.  With ``shared_prefix`` x holds only nimg/2 samples whose two CFG copies
+        (unconditional / conditional) are still identical: everything up to the cross-attention - GroupNorm, proj_in,
+        the whole self-attention, the cross-attention query - is computed ONCE, and the batch doubles where the
+        text context first enters (returns nimg samples)."""
         C, HW, heads, dh = self.C, H * W, self.heads, self.dh
-        M = nimg * HW
+        nb = nimg // 2 if shared_prefix else nimg          # samples in the context-free prefix
+        Mb, M = nb * HW, nimg * HW
         scale = dh ** -0.5
-        h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nimg, HW=HW, groups=self.groups, eps=1e-6, silu=False)
+        h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
         h = hip.linear(h, self.w_in, self.b_in)
         # --- self attention ---
         n1 = hip.layernorm(h, *self.ln[0])
-        qk = hip.linear(n1, self.wqk1)                                    # [M, 2C] = [Q | K]
+        qk = hip.linear(n1, self.wqk1)                                    # [Mb, 2C] = [Q | K]
         ldv = _round_up(HW, 64)
-        hip.gemm(self.wv1, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nimg, sX=0, sW=HW * C,
-                 sC=C * ldv)                                              # V^T [nimg][C][ldv]
-        o = torch.empty((M, C), dtype=BF16, device=x.device)
-        hip.attention(qk, qk, vt_ws, o, B=nimg, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
+        hip.gemm(self.wv1, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C,
+                 sC=C * ldv)                                              # V^T [nb][C][ldv]
+        o = torch.empty((Mb, C), dtype=BF16, device=x.device)
+        hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
                       scale=scale, k_off=C)
         h = hip.linear(o, self.wo1, self.bo1, residual=h)
         # --- cross attention on the text context ---
@@ -140,14 +145,30 @@ class _Transformer:
         q = hip.linear(n2, self.wq2)
         o2 = torch.empty((M, C), dtype=BF16, device=x.device)
         ctx_k, ctx_vt, Lc = self.ctx[nimg]
-        hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
-                      ldo=C, scale=scale)
-        h = hip.linear(o2, self.wo2, self.bo2, residual=h)
+        if not shared_prefix:
+            hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
+                          ldo=C, scale=scale)
+            h = hip.linear(o2, self.wo2, self.bo2, residual=h)
+        else:
+            # same queries against the unconditional and the conditional context; the residual stream h is still
+            # shared, so the output projection reads it with batch stride 0 and writes both halves
+            for half in range(2):
+                hip.attention(q, ctx_k[half * nb * Lc:], ctx_vt[half * nb:], o2[half * Mb:], B=nb, H=heads, Lq=HW, Lk=Lc,
+                              dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2], ldo=C, scale=scale)
+            h2 = torch.empty((M, C), dtype=BF16, device=x.device)
+            hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
+                     sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+            h = h2
         # --- GEGLU feed-forward ---
         n3 = hip.layernorm(h, *self.ln[2])
         g = hip.linear(n3, self.wff1, self.bff1, epi=1)                   # [M, 4C]
         h = hip.linear(g, self.wff2, self.bff2, residual=h)
-        return hip.linear(h, self.w_out, self.b_out, residual=x)
+        if not shared_prefix:
+            return hip.linear(h, self.w_out, self.b_out, residual=x)
+        out = torch.empty((M, C), dtype=BF16, device=x.device)           # residual x is the shared (nb-sample) input
+        hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
+                 sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -252,19 +273,34 @@ class UNetEngine:
                 h, w = 2 * h, 2 * w
 
     # -- one denoise forward -----------------------------------------------------------------
-    def forward(self, x: torch.Tensor, nimg: int, H: int, W: int, step_ptr: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, nimg: int, H: int, W: int, step_ptr: torch.Tensor,
+                cfg_shared: bool = False) -> torch.Tensor:
         """x: bf16 NHWC [nimg*H*W, Cin]; returns eps fp32 NHWC [nimg, H, W, Cout].  The timestep is
-        the ``*step_ptr``-th entry of the schedule given to ``prepare_timesteps``."""
+        the ``*step_ptr``-th entry of the schedule given to ``prepare_timesteps``.
+
+        ``cfg_shared``: the two halves of x are the same latents (classifier-free guidance,
+        ``torch.cat([latents] * 2)`` at stable_diffusion_pipeline.py:414).  Until the text context enters at the first
+        cross-attention the two copies compute identical values, so conv_in, the first ResBlock and the first
+        transformer's self-attention run on nimg/2 samples only."""
         circ = self.tiled
-        h = hip.conv3x3_cin_small(x, self.conv_in_w, self.conv_in_b, nimg=nimg, H=H, W=W, circular=circ)
-        skips = [h]
+        shared = bool(cfg_shared) and nimg % 2 == 0 and bool(self.down[0]["attn"])
+        nb = nimg // 2 if shared else nimg
+        h = hip.conv3x3_cin_small(x[: nb * H * W], self.conv_in_w, self.conv_in_b, nimg=nb, H=H, W=W, circular=circ)
+        if shared:
+            h0 = torch.empty((nimg * H * W, h.shape[1]), dtype=BF16, device=self.device)   # skip tensor for the up path
+            h0[: nb * H * W].copy_(h)
+            h0[nb * H * W:].copy_(h)
+            skips = [h0]
+        else:
+            skips = [h]
         hh, ww = H, W
-        for blk in self.down:
+        for bi, blk in enumerate(self.down):
             for j, r in enumerate(blk["res"]):
-                h = r(h, None, nimg, hh, ww, step_ptr, circ)
+                first = shared and bi == 0 and j == 0
+                h = r(h, None, nb if first else nimg, hh, ww, step_ptr, circ)
                 if blk["attn"]:
                     t = blk["attn"][j]
-                    h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww))
+                    h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww), shared_prefix=first)
                 skips.append(h)
             if blk["down"] is not None:
                 wd, bd = blk["down"]

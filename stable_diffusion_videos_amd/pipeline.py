@@ -274,7 +274,7 @@ class StableDiffusionWalkPipeline:
         n = B * h * w * C
 
         def one_step():
-            eps = self.unet.forward(ent["x2"], nimg, h, w, ent["step"])
+            eps = self.unet.forward(ent["x2"], nimg, h, w, ent["step"], cfg_shared=cfg)
             hip.cfg_ddim_step(eps, ent["latents"], ent["x2"], coefs, ent["step"], eta_noise, guidance, cfg, n)
             hip.step_counter_add(ent["step"], 1)
 

@@ -293,3 +293,26 @@ def test_pipeline_variants(hip, dev):
     assert len(ims) == 4
     with pytest.raises(ValueError, match="negative_prompt"):
         pipe(prompt=["a cat", "a dog"], negative_prompt=["x"], height=64, width=64, num_inference_steps=1)
+
+
+def test_cfg_shared_prefix_is_exact(hip, dev):
+    """Classifier-free guidance feeds the same latents twice (stable_diffusion_pipeline.py:414).  Computing the
+    context-free prefix of the UNet once (cfg_shared=True) must give the same eps as computing it twice."""
+    from stable_diffusion_videos_amd import config as cfgs
+    for c in (cfgs.tiny_unet(), cfgs.sd14_unet()):
+        _, engine = unet_pair(c, dev, seed=4)
+        g = torch.Generator().manual_seed(9)
+        x1 = bf16_round(torch.randn((2, c.in_channels, 16, 16), generator=g))
+        x = torch.cat([x1, x1])
+        ctx = bf16_round(torch.randn((4, 77, c.cross_attention_dim), generator=g))
+        engine.prepare_timesteps([981, 961])
+        engine.prepare_context(ctx.to(dev))
+        step = torch.tensor([1], dtype=torch.int32, device=dev)
+        x2 = x.permute(0, 2, 3, 1).reshape(-1, c.in_channels).to(dev, BF16).contiguous()
+        a = engine.forward(x2, 4, 16, 16, step, cfg_shared=False)
+        b = engine.forward(x2, 4, 16, 16, step, cfg_shared=True)
+        torch.cuda.synchronize()
+        d = float((a - b).abs().max())
+        report(f"cfg_shared vs full ({'sd14' if c.cross_attention_dim == 768 else 'tiny'}): max |d eps| = {d:.3e}")
+        assert d <= 1e-3 * float(a.abs().max())
+        assert float((a[:2] - a[2:]).abs().max()) > 1e-3      # the two halves really differ (different text context)
