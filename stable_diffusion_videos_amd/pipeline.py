@@ -87,6 +87,7 @@ class StableDiffusionWalkPipeline:
         self.noise_device = "cpu"          # portable seeds
         self.embed_interp = "lerp"         # reference torch path lerps embeddings (:467); "slerp" = flax behaviour
         self.use_graphs = os.environ.get("SDV_NO_GRAPH", "0") != "1"
+        self.cfg_shared_prefix = os.environ.get("SDV_NO_CFG_SHARED", "0") != "1"   # see UNetEngine.forward
         self._device = torch.device("cpu")
         self._graphs: Dict[tuple, dict] = {}
         self._uncond_cache: Dict[str, torch.Tensor] = {}
@@ -274,7 +275,7 @@ class StableDiffusionWalkPipeline:
         n = B * h * w * C
 
         def one_step():
-            eps = self.unet.forward(ent["x2"], nimg, h, w, ent["step"], cfg_shared=cfg)
+            eps = self.unet.forward(ent["x2"], nimg, h, w, ent["step"], cfg_shared=cfg and self.cfg_shared_prefix)
             hip.cfg_ddim_step(eps, ent["latents"], ent["x2"], coefs, ent["step"], eta_noise, guidance, cfg, n)
             hip.step_counter_add(ent["step"], 1)
 
