@@ -48,9 +48,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
             float s[8], q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-            for (int p = p_begin + tp; p < p_end; p += g.PT) {
-                const long long pix = (long long)img * HW + p;
-                const bf16x8_raw r = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, pix, c0);
+            // 4 independent 16-byte loads in flight per thread (HBM-bound: memory-level parallelism is the lever)
+            int p = p_begin + tp;
+            for (; p + 3 * g.PT < p_end; p += 4 * g.PT) {
+                bf16x8_raw r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    r[u] = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, (long long)img * HW + p + u * g.PT, c0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    unpack8(r[u], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s[e] += f[e];
+                        q[e] += f[e] * f[e];
+                    }
+                }
+            }
+            for (; p < p_end; p += g.PT) {
+                const bf16x8_raw r = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, (long long)img * HW + p, c0);
                 float f[8];
                 unpack8(r, f);
 #pragma unroll
@@ -125,7 +142,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
             sc[e] = a;
             sh[e] = beta[c] - gmean[ge] * a;
         }
-        for (int p = p_begin + tp; p < p_end; p += g.PT) {
+        int p = p_begin + tp;
+        for (; p + 3 * g.PT < p_end; p += 4 * g.PT) {
+            bf16x8_raw r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                r[u] = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, (long long)img * HW + p + u * g.PT, c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8(r[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = f[e] * sc[e] + sh[e];
+                    f[e] = silu ? silu_f(v) : v;
+                }
+                *(bf16x8_raw*)(Y + ((long long)img * HW + p + u * g.PT) * C + c0) = pack8(f);
+            }
+        }
+        for (; p < p_end; p += g.PT) {
             const long long pix = (long long)img * HW + p;
             const bf16x8_raw r = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, pix, c0);
             float f[8];
@@ -140,54 +175,72 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     }
 }
 
-// one wave per row; C <= 8 * 64 * MAXC chunks
-template <int MAXC>
+// One wave normalises RPW rows per pass: all their 16-byte loads are issued before the first reduction (HBM-bound
+// kernel: memory-level parallelism), gamma / beta stay in registers.  C <= 8 * 64 * MAXC.
+template <int MAXC, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, long long rows, int C,
                                                         uint16_t* __restrict__ Y) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int nchunk = C >> 3;
-    const uint16_t* x = X + row * C;
-    float f[MAXC][8];
-    float s = 0.f;
+    float gm[MAXC][8], bt[MAXC][8];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int ch = lane + i * 64;
-        if (ch < nchunk) {
-            const bf16x8_raw r = *(const bf16x8_raw*)(x + ch * 8);
-            unpack8(r, f[i]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += f[i][e];
+        for (int e = 0; e < 8; ++e) {
+            gm[i][e] = ch < nchunk ? gamma[ch * 8 + e] : 0.f;
+            bt[i][e] = ch < nchunk ? beta[ch * 8 + e] : 0.f;
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+    bf16x8_raw raw[RPW][MAXC];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int ch = lane + i * 64;
-        if (ch < nchunk) {
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = f[i][e] - mean;
-                q += d * d;
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk && row0 + r < rows) raw[r][i] = *(const bf16x8_raw*)(X + (row0 + r) * C + ch * 8);
+        }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        if (row0 + r >= rows) break;
+        float f[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                unpack8(raw[r][i], f[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[i][e];
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    uint16_t* y = Y + row * C;
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int ch = lane + i * 64;
-        if (ch < nchunk) {
-            float o[8];
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = ch * 8 + e;
-                o[e] = (f[i][e] - mean) * rstd * gamma[c] + beta[c];
+                for (int e = 0; e < 8; ++e) {
+                    const float d = f[i][e] - mean;
+                    q += d * d;
+                }
             }
-            *(bf16x8_raw*)(y + ch * 8) = pack8(o);
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        uint16_t* y = Y + (row0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                *(bf16x8_raw*)(y + ch * 8) = pack8(o);
+            }
         }
     }
 }
@@ -236,15 +289,17 @@ extern "C" int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const f
     SDV_REQUIRE(X && gamma && beta && Y, "sdv_layernorm_bf16: null pointer");
     SDV_REQUIRE(C % 8 == 0 && C > 0 && C <= 8 * 64 * 4, "sdv_layernorm_bf16: C=%d unsupported (multiple of 8, <= 2048)", C);
     SDV_REQUIRE(rows > 0, "sdv_layernorm_bf16: rows");
-    dim3 grid((unsigned)((rows + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = C / 8;
     if (nchunk <= 64)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, C, Y);
+        hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, X, gamma, beta, eps,
+                           (long long)rows, C, Y);
     else if (nchunk <= 128)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, C, Y);
+        hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, X, gamma, beta, eps,
+                           (long long)rows, C, Y);
     else
-        hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, C, Y);
+        hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, X, gamma, beta, eps,
+                           (long long)rows, C, Y);
     SDV_CHECK_LAUNCH("sdv_layernorm_bf16");
     return SDV_OK;
 }

@@ -1,0 +1,74 @@
+"""Audio -> interpolation schedule (reference utils.py:12-39).  librosa is not installable
+here, so these are property / known-answer tests of the numpy-scipy restatement ("parity unpinned")."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from stable_diffusion_videos_amd import audio, get_timesteps_arr
+
+WAV = Path(__file__).parent / "samples" / "choice.wav"     # the reference's own fixture (tests/samples/choice.wav)
+
+
+def test_load_matches_wav_contract():
+    y, sr = audio.load_audio(WAV)
+    assert sr == 22050 and y.dtype == np.float32 and y.ndim == 1 and abs(len(y) / sr - 10.0) < 1e-3
+    assert np.abs(y).max() <= 1.0
+    seg, _ = audio.load_audio(WAV, offset=2.0, duration=1.5)
+    assert len(seg) == int(round(1.5 * sr)) and np.array_equal(seg, y[2 * sr:2 * sr + len(seg)])
+
+
+def test_stft_istft_round_trip_and_shapes():
+    y, sr = audio.load_audio(WAV, offset=1.0, duration=2.0)
+    D = audio.stft(y)
+    assert D.shape == (1025, 1 + len(y) // 512) and D.dtype == np.complex64
+    back = audio.istft(D, length=len(y))
+    assert np.abs(back - y)[1024:-1024].max() < 1e-4
+    # a pure tone lands in the right bin
+    t = np.arange(sr) / sr
+    tone = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    assert abs(int(np.abs(audio.stft(tone)).mean(axis=1).argmax()) - round(1000.0 * 2048 / sr)) <= 1
+
+
+def test_hpss_masks_partition_and_separate():
+    sr = 22050
+    t = np.arange(2 * sr) / sr
+    tone = 0.5 * np.sin(2 * np.pi * 440.0 * t)
+    clicks = np.zeros_like(tone)
+    clicks[::sr // 4] = 1.0
+    D = audio.stft((tone + clicks).astype(np.float32))
+    H, P = audio.hpss(D, margin=1.0)
+    assert np.allclose(H + P, D, atol=1e-4)                 # margin 1: the two soft masks sum to one
+    eh, ep = np.abs(H) ** 2, np.abs(P) ** 2
+    tone_bin = round(440.0 * 2048 / sr)
+    assert eh[tone_bin].sum() > 10 * ep[tone_bin].sum()     # the steady tone goes to the harmonic part
+    click_frame = (sr // 4) // 512
+    assert ep[600:, click_frame].sum() > eh[600:, click_frame].sum()   # the click goes to the percussive part
+    H2, P2 = audio.hpss(D, margin=3.0)
+    assert (np.abs(H2) + np.abs(P2) <= np.abs(D) + 1e-4).all()
+
+
+def test_mel_filterbank_known_answers():
+    fb = audio.mel_filterbank()
+    assert fb.shape == (128, 1025) and (fb >= 0).all()
+    assert abs(float(audio._hz_to_mel(1000.0)) - 15.0) < 1e-9 and abs(float(audio._mel_to_hz(15.0)) - 1000.0) < 1e-6
+    assert abs(float(audio._hz_to_mel(6400.0)) - 42.0) < 1e-9           # log region: 27 mels per factor 6.4
+    centers = fb.argmax(axis=1)
+    assert (np.diff(centers) > 0).all()
+    # slaney normalisation: each triangle integrates to ~1 over frequency (bin width sr/n_fft)
+    area = fb.sum(axis=1) * (22050 / 2048)
+    assert np.allclose(area[5:-5], 1.0, atol=0.15)
+
+
+def test_get_timesteps_arr_properties():
+    fps = 6
+    for offset, duration in ((2, 2), (4, 1), (5, 3)):                   # the reference's audio test offsets
+        T = get_timesteps_arr(str(WAV), offset=offset, duration=duration, fps=fps)
+        assert T.shape == (int(duration * fps),) and T.dtype == np.float64
+        assert (np.diff(T) >= -1e-12).all() and T[0] >= 0 and abs(T[-1] - 1.0) < 1e-9
+    lin = get_timesteps_arr(str(WAV), offset=2, duration=2, fps=fps, smooth=1.0)
+    assert np.allclose(lin, np.linspace(0, 1, 12))
+    half = get_timesteps_arr(str(WAV), offset=2, duration=2, fps=fps, smooth=0.5)
+    raw = get_timesteps_arr(str(WAV), offset=2, duration=2, fps=fps)
+    assert np.allclose(half, 0.5 * raw + 0.5 * np.linspace(0, 1, 12))
+    assert not np.allclose(raw, np.linspace(0, 1, 12), atol=0.02)      # audio really bends the schedule
