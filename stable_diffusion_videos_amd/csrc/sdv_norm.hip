@@ -143,23 +143,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
             sh[e] = beta[c] - gmean[ge] * a;
         }
         int p = p_begin + tp;
-        for (; p + 3 * g.PT < p_end; p += 4 * g.PT) {
-            bf16x8_raw r[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                r[u] = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, (long long)img * HW + p + u * g.PT, c0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float f[8];
-                unpack8(r[u], f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = f[e] * sc[e] + sh[e];
-                    f[e] = silu ? silu_f(v) : v;
-                }
-                *(bf16x8_raw*)(Y + ((long long)img * HW + p + u * g.PT) * C + c0) = pack8(f);
-            }
-        }
         for (; p < p_end; p += g.PT) {
             const long long pix = (long long)img * HW + p;
             const bf16x8_raw r = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, pix, c0);
@@ -175,8 +158,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     }
 }
 
-// One wave normalises RPW rows per pass: all their 16-byte loads are issued before the first reduction (HBM-bound
-// kernel: memory-level parallelism), gamma / beta stay in registers.  C <= 8 * 64 * MAXC.
+// One wave normalises RPW rows per pass (RPW = 1 is what ships: measured on MI355X, 4 rows per wave HALVES the achieved
+// bandwidth - 3.8 -> 2.1 TB/s - because a quarter as many waves are in flight).  C <= 8 * 64 * MAXC.
 template <int MAXC, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, long long rows, int C,
@@ -245,6 +228,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     }
 }
 
+// LayerNorm for the SD widths C = 320 * k (k = 1, 2, 4): LPR = 8k lanes share a row, 5 x 16-byte chunks per lane,
+// 64 / LPR rows per wave - every lane is busy (the one-wave-per-row kernel idles 24 of 64 lanes at C = 320) and has five
+// independent loads in flight; row statistics reduce over LPR lanes with log2(LPR) shuffles.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm320_kernel(const uint16_t* __restrict__ X, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, long long rows,
+                                                           uint16_t* __restrict__ Y) {
+    constexpr int C = LPR * 40;
+    constexpr int RPWV = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPWV + lane / LPR;
+    const bool live = row < rows;
+    const uint16_t* x = X + (live ? row : 0) * C;
+    bf16x8_raw raw[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) raw[i] = *(const bf16x8_raw*)(x + (sub + LPR * i) * 8);
+    float f[5][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        unpack8(raw[i], f[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[i][e];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = f[i][e] - mean;
+            q += d * d;
+        }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+    uint16_t* y = Y + row * C;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int c0 = (sub + LPR * i) * 8;
+        const float4 g0 = *(const float4*)(gamma + c0), g1 = *(const float4*)(gamma + c0 + 4);
+        const float4 b0 = *(const float4*)(beta + c0), b1 = *(const float4*)(beta + c0 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gg[e] + bb[e];
+        *(bf16x8_raw*)(y + c0) = pack8(o);
+    }
+}
+
 }  // namespace
 
 extern "C" int sdv_groupnorm_stats(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
@@ -291,11 +329,21 @@ extern "C" int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const f
     SDV_REQUIRE(rows > 0, "sdv_layernorm_bf16: rows");
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = C / 8;
-    if (nchunk <= 64)
-        hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, X, gamma, beta, eps,
+    const bool al16 = ((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
+    if (al16 && (C == 320 || C == 640 || C == 1280)) {
+        const int lpr = C / 40, rpb = 4 * (64 / lpr);
+        const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+        if (lpr == 8)
+            hipLaunchKernelGGL(layernorm320_kernel<8>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, Y);
+        else if (lpr == 16)
+            hipLaunchKernelGGL(layernorm320_kernel<16>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, Y);
+        else
+            hipLaunchKernelGGL(layernorm320_kernel<32>, grid, dim3(256), 0, s, X, gamma, beta, eps, (long long)rows, Y);
+    } else if (nchunk <= 64)
+        hipLaunchKernelGGL((layernorm_kernel<1, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, X, gamma, beta, eps,
                            (long long)rows, C, Y);
     else if (nchunk <= 128)
-        hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, X, gamma, beta, eps,
+        hipLaunchKernelGGL((layernorm_kernel<2, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, X, gamma, beta, eps,
                            (long long)rows, C, Y);
     else
         hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, X, gamma, beta, eps,

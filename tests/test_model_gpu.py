@@ -316,3 +316,24 @@ def test_cfg_shared_prefix_is_exact(hip, dev):
         report(f"cfg_shared vs full ({'sd14' if c.cross_attention_dim == 768 else 'tiny'}): max |d eps| = {d:.3e}")
         assert d <= 1e-3 * float(a.abs().max())
         assert float((a[:2] - a[2:]).abs().max()) > 1e-3      # the two halves really differ (different text context)
+
+
+def test_walk_with_audio_and_video(hip, dev, tmp_path):
+    """Mirror of the reference's test_walk_with_audio (tests/test_pipeline.py:53-68): audio-driven T per clip,
+    batch_size 16, and the mp4 files of the documented layout (:648-666) exist."""
+    wav = Path(__file__).parent / "samples" / "choice.wav"
+    pipe = _tiny_pipeline(dev)
+    fps = 6
+    offsets = [2, 4, 5, 8]
+    steps = [(b - a) * fps for a, b in zip(offsets, offsets[1:])]
+    ret = pipe.walk(["a cat", "a dog", "a horse", "a cow"], seeds=[42, 1337, 4321, 1234], num_interpolation_steps=steps,
+                    output_dir=str(tmp_path), name="audio", fps=fps, audio_filepath=str(wav), audio_start_sec=offsets[0],
+                    batch_size=16, num_inference_steps=2, height=64, width=64)
+    root = tmp_path / "audio"
+    assert ret == str(root / "audio.mp4") and Path(ret).exists() and Path(ret).stat().st_size > 1000
+    for i, n in enumerate(steps):
+        clip = root / f"audio_{i:06d}"
+        assert len(list(clip.glob("frame*.png"))) == n
+        assert (clip / f"audio_{i:06d}.mp4").exists()
+    cfg = json.loads((root / "prompt_config.json").read_text())
+    assert cfg["audio_filepath"] == str(wav) and cfg["audio_start_sec"] == 2 and cfg["num_interpolation_steps"] == steps
