@@ -29,12 +29,14 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SDV_FORCE_DEVICE") is not None:      # functional tests of the N-rank path on a 1-GPU box
+        local = int(os.environ["SDV_FORCE_DEVICE"])
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SDV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))
