@@ -51,7 +51,7 @@ int sdv_abi_version(void);
  * X2/C1     optional second source: channels [0,C1) come from X, [C1,K) from X2 (skip-connection
  *           concat without materialising it).  C1 % 64 == 0.
  * epi       0: bf16 out = acc*alpha (+bias) (+R)      [ldc, residual R with ldr]
- *           1: GEGLU: W rows pre-interleaved in 32-row blocks [value | gate]; out is [M][N/2]
+ *           1: GEGLU: W rows pre-interleaved per 32-row tile as [16 value | 16 gate]; out is [M][N/2]
  *           2: as 0, then SiLU
  * bias      fp32; bias_mode 1 = per n, 2 = per m.  If step_ptr != NULL the bias row used is
  *           bias + (*step_ptr) * bias_step_stride (per-denoise-step time-embedding bias table).

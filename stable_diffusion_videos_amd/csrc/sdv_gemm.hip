@@ -290,13 +290,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
         const int ncols_out = geglu ? (p.N >> 1) : p.N;
         const bool aligned = ((p.ldc & 7) == 0) && ((ncols_out & 7) == 0) && (!R || (p.ldr & 7) == 0) &&
                              ((((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0) &&
-                             (((p.sC | p.sR) & 7) == 0) && (!geglu || (TN % 2 == 0));
+                             (((p.sC | p.sR) & 7) == 0);
         if (aligned) {
             float* stg = (float*)smem + wave * (32 * 64);
             __syncthreads();  // every wave has left the K loop: the tile buffers may be overwritten
             // one pass: n-tiles [nt0, nt0+ntc) of m-tile mt -> OC output columns starting at ocol
             auto pass = [&](auto oc_tag, int mt, int nt0, int ocol) {
-                constexpr int OC = decltype(oc_tag)::value;   // 64 or 32 output columns
+                constexpr int OC = decltype(oc_tag)::value;   // 64 / 32 / 16 output columns
                 constexpr int CPO = OC / 8;                   // 16-byte bf16 chunks per output row
                 constexpr int ITERS = 32 * CPO / 64;
                 const int mbase = m0 + wm * TM * 32 + mt * 32;
@@ -313,24 +313,27 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                 const int mrow = mbase + l31;
                 const float bm_ = (bias && p.bias_mode == 2 && mrow < p.M) ? bias[mrow] : 0.f;
                 if (geglu) {
-                    if constexpr (TN % 2 == 0) {
+                    // W rows are interleaved [16 value | 16 gate] per 32-row MFMA tile: accumulator quads g and g+2 of
+                    // a lane hold the value and the gate of the SAME 4 channels -> 16 output columns per n-tile
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int nv = wcol0 + nt0 * 32 + 8 * g4 + 4 * lhi;
+                    for (int j = 0; j < OC / 16; ++j)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const int nt = nt0 + j;
+                            const int nv = wcol0 + nt * 32 + 8 * g + 4 * lhi;
                             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
-                            if (bias && nv + 35 < p.N) {
+                            if (bias && nv + 19 < p.N) {
                                 bv = *(const float4*)(bias + nv);
-                                bg = *(const float4*)(bias + nv + 32);
+                                bg = *(const float4*)(bias + nv + 16);
                             }
                             float4 o;
-                            o.x = (acc[nt0][mt][4 * g4 + 0] * alpha + bv.x) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 0] * alpha + bg.x);
-                            o.y = (acc[nt0][mt][4 * g4 + 1] * alpha + bv.y) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 1] * alpha + bg.y);
-                            o.z = (acc[nt0][mt][4 * g4 + 2] * alpha + bv.z) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 2] * alpha + bg.z);
-                            o.w = (acc[nt0][mt][4 * g4 + 3] * alpha + bv.w) * gelu_erf_f(acc[nt0 + 1][mt][4 * g4 + 3] * alpha + bg.w);
-                            const int chunk = 2 * g4 + lhi;
+                            o.x = (acc[nt][mt][4 * g + 0] * alpha + bv.x) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 0] * alpha + bg.x);
+                            o.y = (acc[nt][mt][4 * g + 1] * alpha + bv.y) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 1] * alpha + bg.y);
+                            o.z = (acc[nt][mt][4 * g + 2] * alpha + bv.z) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 2] * alpha + bg.z);
+                            o.w = (acc[nt][mt][4 * g + 3] * alpha + bv.w) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 3] * alpha + bg.w);
+                            const int chunk = j * 4 + 2 * g + lhi;
                             *(float4*)(stg + l31 * 64 + ((chunk ^ (l31 & 7)) << 2)) = o;
                         }
-                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < OC / 32; ++j)
@@ -381,11 +384,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 if (geglu) {
-                    if constexpr (TN % 2 == 0) {
 #pragma unroll
-                        for (int nt = 0; nt < TN; nt += 2)
-                            pass(std::integral_constant<int, 32>{}, mt, nt, (wcol0 >> 1) + (nt >> 1) * 32);
-                    }
+                    for (int nt = 0; nt + 1 < TN; nt += 2) pass(std::integral_constant<int, 32>{}, mt, nt, (wcol0 >> 1) + nt * 16);
+                    if constexpr (TN % 2 == 1) pass(std::integral_constant<int, 16>{}, mt, TN - 1, (wcol0 >> 1) + (TN - 1) * 16);
                 } else {
 #pragma unroll
                     for (int nt = 0; nt + 1 < TN; nt += 2) pass(std::integral_constant<int, 64>{}, mt, nt, wcol0 + nt * 32);
@@ -398,37 +399,35 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
 
     // ---- fallback epilogue straight from the MFMA registers (odd leading dims / N, e.g. the 77-token V^T) ----
     if (geglu) {
-        if constexpr (TN % 2 == 0) {
-            const int nout = p.N >> 1;
+        const int nout = p.N >> 1;
 #pragma unroll
-            for (int nt = 0; nt < TN; nt += 2)
+        for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) {
-                    const int m = m0 + wm * TM * 32 + mt * 32 + l31;
-                    if (m >= p.M) continue;
+            for (int mt = 0; mt < TM; ++mt) {
+                const int m = m0 + wm * TM * 32 + mt * 32 + l31;
+                if (m >= p.M) continue;
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int nv = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;  // value row (permuted index)
-                        const int oc = ((wcol0 + nt * 32) >> 1) + 8 * g4 + 4 * lhi;
-                        if (oc >= nout) continue;
-                        float v[4];
+                for (int g = 0; g < 2; ++g) {
+                    const int nv = wcol0 + nt * 32 + 8 * g + 4 * lhi;  // value row (interleaved index), gate = +16
+                    const int oc = ((wcol0 + nt * 32) >> 1) + 8 * g + 4 * lhi;
+                    if (oc >= nout) continue;
+                    float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float a = acc[nt][mt][4 * g4 + e] * alpha;
-                            float g = acc[nt + 1][mt][4 * g4 + e] * alpha;
-                            if (bias) {
-                                a += bias[nv + e];
-                                g += bias[nv + 32 + e];
-                            }
-                            v[e] = a * gelu_erf_f(g);
+                    for (int e = 0; e < 4; ++e) {
+                        float a = acc[nt][mt][4 * g + e] * alpha;
+                        float gt = acc[nt][mt][4 * (g + 2) + e] * alpha;
+                        if (bias) {
+                            a += bias[nv + e];
+                            gt += bias[nv + 16 + e];
                         }
-                        uint2 o;
-                        o.x = pack_bf16x2(v[0], v[1]);
-                        o.y = pack_bf16x2(v[2], v[3]);
-                        *(uint2*)(C + (long long)m * p.ldc + oc) = o;
+                        v[e] = a * gelu_erf_f(gt);
                     }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)(C + (long long)m * p.ldc + oc) = o;
                 }
-        }
+            }
         return;
     }
 
@@ -538,7 +537,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     }
     SDV_REQUIRE(320LL * a.ldw * 2 < 0x7fffffffLL, "sdv_gemm_bf16: ldw too large");
     if (a.epi == 1) {
-        SDV_REQUIRE(a.N % 64 == 0, "sdv_gemm_bf16: GEGLU needs N %% 64 == 0");
+        SDV_REQUIRE(a.N % 32 == 0, "sdv_gemm_bf16: GEGLU needs N %% 32 == 0");
         SDV_REQUIRE(a.ldc % 4 == 0, "sdv_gemm_bf16: GEGLU needs ldc %% 4 == 0");
     }
     if (a.bias_mode == 0 && a.bias) a.bias_mode = 1;
@@ -559,7 +558,6 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
                                      {1, 128, 128, 3.4f}, {2, 128, 64, 2.4f}, {3, 64, 64, 2.0f}};
         double best = 1e300;
         for (const Cand& c : cands) {
-            if (a.epi == 1 && (c.id == 6 || c.id == 9 || c.id == 3)) continue;   // GEGLU pairs n-tiles: even TN only
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
             const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {
@@ -568,8 +566,6 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
             }
         }
     }
-    if (a.epi == 1 && tile == 3) tile = 2;
-    if (a.epi == 1 && (tile == 6 || tile == 9)) tile = (a.N % 256 == 0) ? 7 : 1;   // GEGLU pairs n-tiles: even TN only
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2, 64>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64

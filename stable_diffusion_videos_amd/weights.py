@@ -231,10 +231,11 @@ def vec(v: torch.Tensor, device) -> torch.Tensor:
 
 
 def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
-    """ff.net.0.proj rows are [value(4C) | gate(4C)]; the GEGLU epilogue wants 32-row blocks
-    [value_b | gate_b] so that both halves of a channel meet in the same MFMA lane/register."""
+    """ff.net.0.proj rows are [value(4C) | gate(4C)]; the GEGLU epilogue wants every 32-row MFMA tile to hold
+    [16 value rows | the 16 gate rows of the same channels], so that value and gate of a channel meet in the same
+    lane (accumulator quads g and g+2 of the 32x32 MFMA C layout)."""
     half = t.shape[0] // 2
-    assert half % 32 == 0
-    val = t[:half].reshape(half // 32, 32, *t.shape[1:])
-    gate = t[half:].reshape(half // 32, 32, *t.shape[1:])
+    assert half % 16 == 0
+    val = t[:half].reshape(half // 16, 16, *t.shape[1:])
+    gate = t[half:].reshape(half // 16, 16, *t.shape[1:])
     return torch.stack([val, gate], dim=1).reshape(t.shape).contiguous()

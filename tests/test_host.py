@@ -91,11 +91,11 @@ def test_weight_schema_and_relayout():
     w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
     r = weights.conv_w(w, "cpu").float()
     assert r.shape == (2, 27) and float(r[1, (2 * 3 + 1) * 3 + 2]) == float(w[1, 2, 2, 1])
-    # GEGLU interleave: 32-row blocks [value_b | gate_b]
+    # GEGLU interleave: every 32-row tile = [16 value rows | their 16 gate rows]
     t = torch.arange(128, dtype=torch.float32)[:, None].repeat(1, 2)
     g = weights.geglu_interleave(t)
-    assert g[:32, 0].tolist() == list(range(0, 32)) and g[32:64, 0].tolist() == list(range(64, 96))
-    assert g[64:96, 0].tolist() == list(range(32, 64)) and g[96:, 0].tolist() == list(range(96, 128))
+    assert g[:16, 0].tolist() == list(range(0, 16)) and g[16:32, 0].tolist() == list(range(64, 80))
+    assert g[32:48, 0].tolist() == list(range(16, 32)) and g[48:64, 0].tolist() == list(range(80, 96))
 
 
 def test_scheduler_coefficients_equal_oracle_step():
