@@ -125,6 +125,9 @@ int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta,
 int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Cin]*/, const float* bias,
                           sdv_bf16* Y, int32_t nimg, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
                           int32_t circular, void* stream);
+/* im2col of a 4-channel NHWC image for a 3x3 pad-1 conv: Y[pixel][64] = [9 taps x 4 channels | 28 zeros]; the conv is
+ * then sdv_gemm_bf16 with K = 64 against weights zero-padded the same way (UNet conv_in, VAE decoder.conv_in). */
+int sdv_im2col3x3_c4(const sdv_bf16* X, sdv_bf16* Y, int32_t nimg, int32_t H, int32_t Wd, int32_t circular, void* stream);
 int sdv_conv3x3_cout_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Cin]*/, const float* bias,
                            float* out_f32, uint8_t* out_u8, int32_t nimg, int32_t H, int32_t Wd,
                            int32_t Cin, int32_t Cout, int32_t out_mode, int32_t circular, void* stream);

@@ -230,6 +230,39 @@ __global__ __launch_bounds__(kThreads) void latent_affine_kernel(const float* __
     }
 }
 
+
+// ---- im2col for the 4-channel latent convs (UNet conv_in, VAE decoder.conv_in): every output pixel gets one 128-byte
+//      row [tap0 c0..c3 | tap1 c0..c3 | ... | tap8 | zeros up to 64] so that the conv becomes a K = 64 dense GEMM on
+//      the matrix cores (weights zero-padded the same way).  HBM-bound: 8-byte gathers in, 16-byte stores out. ----
+__global__ __launch_bounds__(kThreads) void im2col3x3_c4_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y,
+                                                                int nimg, int H, int Wd, int circular) {
+    const long long npix = (long long)nimg * H * Wd;
+    for (long long pix = (long long)blockIdx.x * kThreads + threadIdx.x; pix < npix; pix += (long long)gridDim.x * kThreads) {
+        const int img = (int)(pix / ((long long)H * Wd));
+        const int rem = (int)(pix - (long long)img * H * Wd);
+        const int y = rem / Wd, x = rem - y * Wd;
+        uint2 v[10];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            bool ok = true;
+            if (circular) {
+                iy = (iy + H) % H;
+                ix = (ix + Wd) % Wd;
+            } else {
+                ok = iy >= 0 && iy < H && ix >= 0 && ix < Wd;
+            }
+            v[tap] = ok ? *(const uint2*)(X + (((long long)img * H + iy) * Wd + ix) * 4) : make_uint2(0u, 0u);
+        }
+        v[9] = make_uint2(0u, 0u);
+        uint4* out = (uint4*)(Y + pix * 64);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) out[i] = make_uint4(v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y);
+#pragma unroll
+        for (int i = 5; i < 8; ++i) out[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // ---- direct conv3x3, tiny Cin (4 -> 320 / 512): thread = (pixel, 8 output channels) ------------
 // weights [Cout][9][Cin] bf16 are transposed into LDS as fp32 [9*Cin][Cout] once per block.
 template <int CIN>
@@ -459,6 +492,16 @@ extern "C" int sdv_latent_affine(const float* X, const float* Wpq, const float* 
     hipLaunchKernelGGL(latent_affine_kernel, dim3(grid_for(npix)), dim3(kThreads), 0, (hipStream_t)stream, X, Wpq, bias,
                        in_scale, Y, (long long)npix, C);
     SDV_CHECK_LAUNCH("sdv_latent_affine");
+    return SDV_OK;
+}
+
+extern "C" int sdv_im2col3x3_c4(const sdv_bf16* X, sdv_bf16* Y, int32_t nimg, int32_t H, int32_t Wd, int32_t circular,
+                                void* stream) {
+    SDV_REQUIRE(X && Y && nimg > 0 && H > 0 && Wd > 0, "sdv_im2col3x3_c4: bad args");
+    const long long npix = (long long)nimg * H * Wd;
+    hipLaunchKernelGGL(im2col3x3_c4_kernel, dim3(grid_for(npix, kThreads, 8192)), dim3(kThreads), 0, (hipStream_t)stream, X, Y,
+                       nimg, H, Wd, circular);
+    SDV_CHECK_LAUNCH("sdv_im2col3x3_c4");
     return SDV_OK;
 }
 

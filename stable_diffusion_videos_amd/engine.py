@@ -23,7 +23,7 @@ import torch
 
 from . import hip
 from .config import UNetConfig, VAEConfig
-from .weights import StateDict, conv_w, geglu_interleave, lin_w, vec
+from .weights import StateDict, conv_w, conv_w_c4, geglu_interleave, lin_w, vec
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -183,7 +183,8 @@ class UNetEngine:
         ch = cfg.block_out_channels
         g, eps = cfg.norm_num_groups, cfg.norm_eps
         dev = self.device
-        self.conv_in_w = conv_w(sd["conv_in.weight"], dev)
+        self.conv_in_c4 = cfg.in_channels == 4
+        self.conv_in_w = conv_w_c4(sd["conv_in.weight"].cpu(), dev) if self.conv_in_c4 else conv_w(sd["conv_in.weight"], dev)
         self.conv_in_b = vec(sd["conv_in.bias"], dev)
         self.t_w1, self.t_b1 = lin_w(sd["time_embedding.linear_1.weight"], dev), vec(sd["time_embedding.linear_1.bias"], dev)
         self.t_w2, self.t_b2 = lin_w(sd["time_embedding.linear_2.weight"], dev), vec(sd["time_embedding.linear_2.bias"], dev)
@@ -285,7 +286,8 @@ class UNetEngine:
         circ = self.tiled
         shared = bool(cfg_shared) and nimg % 2 == 0 and bool(self.down[0]["attn"])
         nb = nimg // 2 if shared else nimg
-        h = hip.conv3x3_cin_small(x[: nb * H * W], self.conv_in_w, self.conv_in_b, nimg=nb, H=H, W=W, circular=circ)
+        conv_in = hip.conv3x3_c4 if self.conv_in_c4 else hip.conv3x3_cin_small
+        h = conv_in(x[: nb * H * W], self.conv_in_w, self.conv_in_b, nimg=nb, H=H, W=W, circular=circ)
         if shared:
             h0 = torch.empty((nimg * H * W, h.shape[1]), dtype=BF16, device=self.device)   # skip tensor for the up path
             h0[: nb * H * W].copy_(h)
@@ -342,7 +344,10 @@ class VAEDecoderEngine:
         lc = cfg.latent_channels
         self.pq_w = sd["post_quant_conv.weight"].reshape(lc, lc).contiguous().to(dev, F32)
         self.pq_b = vec(sd["post_quant_conv.bias"], dev)
-        self.conv_in_w, self.conv_in_b = conv_w(sd["decoder.conv_in.weight"], dev), vec(sd["decoder.conv_in.bias"], dev)
+        self.conv_in_c4 = lc == 4
+        self.conv_in_w = (conv_w_c4(sd["decoder.conv_in.weight"].cpu(), dev) if self.conv_in_c4
+                          else conv_w(sd["decoder.conv_in.weight"], dev))
+        self.conv_in_b = vec(sd["decoder.conv_in.bias"], dev)
         self.mid_res = [_Res(sd, f"decoder.mid_block.resnets.{i}", dev, g, 1e-6, False) for i in range(2)]
         a = "decoder.mid_block.attentions.0"
         self.a_g, self.a_b = vec(sd[a + ".group_norm.weight"], dev), vec(sd[a + ".group_norm.bias"], dev)
@@ -385,7 +390,8 @@ class VAEDecoderEngine:
         circ = self.tiled
         z = torch.empty((B * h * w, lc), dtype=BF16, device=self.device)
         hip.latent_affine(latents.contiguous(), self.pq_w, self.pq_b, 1.0 / self.cfg.scaling_factor, z, B * h * w, lc)
-        x = hip.conv3x3_cin_small(z, self.conv_in_w, self.conv_in_b, nimg=B, H=h, W=w, circular=circ)
+        conv_in = hip.conv3x3_c4 if self.conv_in_c4 else hip.conv3x3_cin_small
+        x = conv_in(z, self.conv_in_w, self.conv_in_b, nimg=B, H=h, W=w, circular=circ)
         x = self.mid_res[0](x, None, B, h, w, None, circ)
         x = self._attention(x, B, h, w)
         x = self.mid_res[1](x, None, B, h, w, None, circ)

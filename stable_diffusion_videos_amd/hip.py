@@ -46,6 +46,7 @@ _SIGNATURES = {
                             [C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "sdv_layernorm_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sdv_conv3x3_cin_small": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
+    "sdv_im2col3x3_c4": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "sdv_conv3x3_cout_small": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
     "sdv_latent_affine": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "sdv_slerp_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -114,6 +115,7 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 _zero_pages = {}
+_GEGLU_TILE = int(__import__("os").environ.get("SDV_GEGLU_TILE", "0"))
 
 # Optional launch observer used by bench.py's roofline pass: called as hook(kind, info_dict, launch_fn).  The
 # hook must call launch_fn() itself (it may bracket it with HIP events).  None = no overhead.
@@ -176,6 +178,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if K != K1 + K2:
         raise SdvHipError(f"linear: K mismatch {K} vs {K1}+{K2}")
     n_out = N // 2 if epi == 1 else N
+    if epi == 1 and tile == 0 and _GEGLU_TILE:
+        tile = _GEGLU_TILE                       # experiment knob (SDV_GEGLU_TILE)
     if out is None:
         out = torch.empty((M, n_out), dtype=BF16, device=x.device)
     gemm(x, w, out, M=M, N=N, K=K, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
@@ -282,6 +286,19 @@ def conv3x3_cin_small(x, w, bias, *, nimg, H, W, circular=False, out=None):
             lambda: _check(lib.sdv_conv3x3_cin_small(xp, wp, bp, op, nimg, H, W, Cin, Cout, int(circular), _stream()),
                            "sdv_conv3x3_cin_small"))
     return out
+
+
+def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False):
+    """3x3 pad-1 conv of a 4-channel NHWC tensor on the matrix cores: im2col to 64-wide rows + K = 64 GEMM.
+    ``w_pad``: [Cout, 64] = OHWI weights [Cout, 36] zero-padded (see ``weights.conv_w_c4``)."""
+    lib = load()
+    if x.shape[1] != 4:
+        raise SdvHipError(f"conv3x3_c4: expected 4 input channels, got {x.shape[1]}")
+    cols = torch.empty((nimg * H * W, 64), dtype=BF16, device=x.device)
+    xp, cp = _ptr(x, BF16, "X"), _ptr(cols, BF16)
+    _launch("im2col_c4", dict(bytes=2.0 * nimg * H * W * (4 + 64)),
+            lambda: _check(lib.sdv_im2col3x3_c4(xp, cp, nimg, H, W, int(circular), _stream()), "sdv_im2col3x3_c4"))
+    return linear(cols, w_pad, bias)
 
 
 def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_u8=None, circular=False):

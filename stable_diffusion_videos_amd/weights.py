@@ -222,6 +222,16 @@ def conv_w(w: torch.Tensor, device) -> torch.Tensor:
     return w.permute(0, 2, 3, 1).reshape(co, -1).contiguous().to(device=device, dtype=torch.bfloat16)
 
 
+def conv_w_c4(w: torch.Tensor, device) -> torch.Tensor:
+    """[Cout, 4, 3, 3] -> [Cout, 64]: OHWI rows (tap-major, 36 values) zero-padded to one 64-wide K tile, the layout
+    ``sdv_im2col3x3_c4`` produces for the activations."""
+    co = w.shape[0]
+    flat = w.permute(0, 2, 3, 1).reshape(co, -1)
+    out = torch.zeros((co, 64), dtype=flat.dtype)
+    out[:, : flat.shape[1]] = flat
+    return out.contiguous().to(device=device, dtype=torch.bfloat16)
+
+
 def lin_w(w: torch.Tensor, device) -> torch.Tensor:
     return w.reshape(w.shape[0], -1).contiguous().to(device=device, dtype=torch.bfloat16)
 

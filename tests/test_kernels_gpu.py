@@ -166,6 +166,10 @@ def test_conv_small_channel_kernels(hip, dev):
         out = hip.conv3x3_cin_small(x.reshape(-1, 4).to(BF16), conv_w(w, dev), b, nimg=n, H=H, W=W, circular=circular)
         ref = conv_ref(x, w, b, 1, circular)
         assert rel_l2(out.float().reshape(ref.shape), ref) < 3e-3
+        # the same conv on the matrix cores: im2col (4 ch -> one 64-wide K tile) + dense GEMM
+        from stable_diffusion_videos_amd.weights import conv_w_c4
+        out2 = hip.conv3x3_c4(x.reshape(-1, 4).to(BF16), conv_w_c4(w.cpu(), dev), b, nimg=n, H=H, W=W, circular=circular)
+        assert rel_l2(out2.float().reshape(ref.shape), ref) < 3e-3
         # 320 -> 4, fp32 out (UNet conv_out)
         x, w, b = rnd((n, H, W, 320), dev, 33), rnd((4, 320, 3, 3), dev, 34, (9 * 320) ** -0.5), rnd((4,), dev, 35)
         o = torch.empty((n, H, W, 4), dtype=F32, device=dev)
