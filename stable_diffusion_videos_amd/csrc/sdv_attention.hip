@@ -15,6 +15,8 @@
 // One workgroup = 4 waves x 32 queries = 128 queries of one head; K / V^T tiles of 64 keys are
 // register-staged (global -> VGPR issued before the MFMA phase, VGPR -> LDS after the barrier).
 // Head sizes: dh = 40 (K padded to 48 for QK^T, to 64 rows for PV), 64, 80 (96 rows for PV), 160.
+#include <stdlib.h>
+
 #include "sdv_common.h"
 
 namespace {
@@ -39,7 +41,7 @@ struct AttnCfg {
     static constexpr int VPT = (VCH + 255) / 256;
 };
 
-template <int DH>
+template <int DH, bool PRIO>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         if (t + 1 < ntiles) load_tile((t + 1) * 64);
 
         // ---- S^T = K . Q^T for two 32-key subtiles ----
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);   // matrix-pipe clusters win issue arbitration (guide T5)
         f32x16_t s[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                     s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
         }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax (base-2), lane-local.  Raw scores stay unscaled; the softmax scale is folded into
         //      the exp2 argument with one FMA.  Keys beyond Lk only exist in the last tile (uniform branch). ----
         const int kv0 = t * 64;
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             }
         l_run += psum;
         // ---- O^T += V^T . P^T ----
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 const bf16x8_t vf = *(const bf16x8_t*)(ldsV + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ju], o[dt], 0, 0, 0);
             }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- normalise and store O[q][h*DH + d] ----
@@ -240,8 +246,13 @@ int launch_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, u
     using Cfg = AttnCfg<DH>;
     dim3 grid((Lq + 127) / 128, H, B);
     const int lds = Cfg::K_BYTES + Cfg::V_BYTES;
-    hipLaunchKernelGGL((attention_kernel<DH>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
-                       scale * 1.4426950408889634f);
+    static const bool prio = getenv("SDV_ATTN_PRIO") && atoi(getenv("SDV_ATTN_PRIO")) != 0;   // experiment knob
+    if (prio)
+        hipLaunchKernelGGL((attention_kernel<DH, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
+                           scale * 1.4426950408889634f);
+    else
+        hipLaunchKernelGGL((attention_kernel<DH, false>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
+                           scale * 1.4426950408889634f);
     SDV_CHECK_LAUNCH("sdv_attention_bf16");
     return SDV_OK;
 }

@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Time the UNet's self-attention shapes (HIP events).  usage: attn_bench.py [nimg]"""
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from stable_diffusion_videos_amd import hip  # noqa: E402
+
+nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dev = torch.device("cuda")
+for dh, L, heads in ((40, 4096, 8), (80, 1024, 8), (160, 256, 8)):
+    C = dh * heads
+    qk = torch.randn((nimg * L, 2 * C), device=dev).to(torch.bfloat16)
+    vt = torch.randn((nimg, C, L), device=dev).to(torch.bfloat16)
+    o = torch.empty((nimg * L, C), dtype=torch.bfloat16, device=dev)
+    fn = lambda: hip.attention(qk, qk, vt, o, B=nimg, H=heads, Lq=L, Lk=L, dh=dh, ldq=2 * C, ldk=2 * C, ldv=L, ldo=C,
+                               scale=dh ** -0.5, k_off=C)
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 5
+    print(f"dh={dh} L={L} nimg={nimg}: {ms:.3f} ms  {4.0 * nimg * heads * L * L * dh / ms / 1e9:.0f} TFLOP/s algorithmic")
