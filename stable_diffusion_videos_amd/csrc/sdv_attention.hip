@@ -41,11 +41,12 @@ struct AttnCfg {
     static constexpr int VPT = (VCH + 255) / 256;
 };
 
-template <int DH, bool PRIO>
+template <int DH, int QT, bool PRIO>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                                                         float scale_log2e) {
+    // QT = 32-query tiles per wave: the K / V^T fragments read from LDS are reused for QT MFMAs each.
     using Cfg = AttnCfg<DH>;
     constexpr int DKS = Cfg::DKS, DVT = Cfg::DVT, KROW = Cfg::KROW, VROW = Cfg::VROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,24 +60,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int lhi = lane >> 5;
     const int h = blockIdx.y;
     const int b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = (blockIdx.x * 4 + wave) * (32 * QT);
 
     // zero the LDS pads once: K columns [DH, DKP) and V^T rows [DH, DVP) are never rewritten
     for (int i = tid; i < (Cfg::K_BYTES + Cfg::V_BYTES) / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
 
-    // ---- Q fragments (B operand): lane owns query row q0 + l31, d = ks*16 + lhi*8 .. +7 ----
-    bf16x8_t qf[DKS];
-    {
-        int q = q0 + l31;
+    // ---- Q fragments (B operand): lane owns query rows q0 + qt*32 + l31, d = ks*16 + lhi*8 .. +7 ----
+    bf16x8_t qf[QT][DKS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int q = q0 + qt * 32 + l31;
         q = q < Lq ? q : Lq - 1;
         const uint16_t* qrow = Q + ((long long)b * Lq + q) * ldq + h * DH;
 #pragma unroll
         for (int ks = 0; ks < DKS; ++ks) {
             const int d0 = ks * 16 + lhi * 8;
             if (d0 < DH)
-                qf[ks] = *(const bf16x8_t*)(qrow + d0);
+                qf[qt][ks] = *(const bf16x8_t*)(qrow + d0);
             else
-                qf[ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                qf[qt][ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
 
@@ -126,13 +128,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         }
     };
 
-    f32x16_t o[DVT];
+    f32x16_t o[QT][DVT];
+    float m_run[QT], l_run[QT];  // l_run: this lane's partial row sum (its 32 of the 64 keys per tile)
 #pragma unroll
-    for (int t = 0; t < DVT; ++t)
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
-    float m_run = -INFINITY;
-    float l_run = 0.f;  // this lane's partial row sum (its 32 of the 64 keys per tile)
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[qt][t][e] = 0.f;
+    }
 
     const int ntiles = (Lk + 63) / 64;
     load_tile(0);
@@ -142,119 +148,143 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         __syncthreads();
         if (t + 1 < ntiles) load_tile((t + 1) * 64);
 
-        // ---- S^T = K . Q^T for two 32-key subtiles ----
+        // ---- S^T = K . Q^T for two 32-key subtiles (each K fragment feeds QT MFMAs) ----
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);   // matrix-pipe clusters win issue arbitration (guide T5)
-        f32x16_t s[2];
+        f32x16_t s[QT][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int ks = 0; ks < DKS; ++ks) {
                 const bf16x8_t kf = *(const bf16x8_t*)(ldsK + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
-                if (ks == 0)
-                    s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], kZero16, 0, 0, 0);   // C = inline 0
-                else
-                    s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    if (ks == 0)
+                        s[qt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qt][0], kZero16, 0, 0, 0);   // C = inline 0
+                    else
+                        s[qt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qt][ks], s[qt][j], 0, 0, 0);
+                }
             }
         }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax (base-2), lane-local.  Raw scores stay unscaled; the softmax scale is folded into
         //      the exp2 argument with one FMA.  Keys beyond Lk only exist in the last tile (uniform branch). ----
         const int kv0 = t * 64;
-        if (kv0 + 64 > Lk) {
+        bf16x8_t pf[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            if (kv0 + 64 > Lk) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        s[qt][j][r] = key < Lk ? s[qt][j][r] : -INFINITY;
+                    }
+            }
+            float mx = s[qt][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qt][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qt][1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;      // scale > 0: max commutes with it
+            // deferred rescale: keep the old running max while the tile max grows by < kDefer (P stays <= 2^kDefer,
+            // exact in fp32 accumulation); when it fires, O and l are rescaled BEFORE this tile's P exists.
+            if (!__all(mx - m_run[qt] <= kDefer)) {
+                const float m_new = fmaxf(m_run[qt], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
+            }
+            float psum = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    s[j][r] = key < Lk ? s[j][r] : -INFINITY;
+                for (int u = 0; u < 2; ++u) {
+                    float pv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][j][8 * u + e], scale_log2e, -m_run[qt]));
+                        psum += pv[e];
+                    }
+                    u32x4_t pr;
+                    pr[0] = pack_bf16x2(pv[0], pv[1]);
+                    pr[1] = pack_bf16x2(pv[2], pv[3]);
+                    pr[2] = pack_bf16x2(pv[4], pv[5]);
+                    pr[3] = pack_bf16x2(pv[6], pv[7]);
+                    pf[qt][j * 2 + u] = __builtin_bit_cast(bf16x8_t, pr);
                 }
+            l_run[qt] += psum;
         }
-        float mx = s[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;      // scale > 0: max commutes with it
-        // deferred rescale: keep the old running max while the tile max grows by < kDefer (P stays <= 2^kDefer,
-        // exact in fp32 accumulation); when it fires, O and l are rescaled BEFORE this tile's P exists.
-        if (!__all(mx - m_run <= kDefer)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < DVT; ++dt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
-        }
-        float psum = 0.f;
-        bf16x8_t pf[4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float pv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][8 * u + e], scale_log2e, -m_run));
-                    psum += pv[e];
-                }
-                u32x4_t pr;
-                pr[0] = pack_bf16x2(pv[0], pv[1]);
-                pr[1] = pack_bf16x2(pv[2], pv[3]);
-                pr[2] = pack_bf16x2(pv[4], pv[5]);
-                pr[3] = pack_bf16x2(pv[6], pv[7]);
-                pf[j * 2 + u] = __builtin_bit_cast(bf16x8_t, pr);
-            }
-        l_run += psum;
-        // ---- O^T += V^T . P^T ----
+        // ---- O^T += V^T . P^T (each V^T fragment feeds QT MFMAs) ----
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
             for (int ju = 0; ju < 4; ++ju) {
                 const bf16x8_t vf = *(const bf16x8_t*)(ldsV + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ju], o[dt], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt][ju], o[qt][dt], 0, 0, 0);
             }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- normalise and store O[q][h*DH + d] ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + l31;
-    if (q < Lq) {
-        uint16_t* orow = O + ((long long)b * Lq + q) * ldo + h * DH;
 #pragma unroll
-        for (int dt = 0; dt < DVT; ++dt)
+    for (int qt = 0; qt < QT; ++qt) {
+        const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + qt * 32 + l31;
+        if (q < Lq) {
+            uint16_t* orow = O + ((long long)b * Lq + q) * ldo + h * DH;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = dt * 32 + 8 * g4 + 4 * lhi;
-                if (d < DH) {
-                    uint2 w;
-                    w.x = pack_bf16x2(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
-                    w.y = pack_bf16x2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
-                    *(uint2*)(orow + d) = w;
+            for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = dt * 32 + 8 * g4 + 4 * lhi;
+                    if (d < DH) {
+                        uint2 w;
+                        w.x = pack_bf16x2(o[qt][dt][4 * g4 + 0] * inv, o[qt][dt][4 * g4 + 1] * inv);
+                        w.y = pack_bf16x2(o[qt][dt][4 * g4 + 2] * inv, o[qt][dt][4 * g4 + 3] * inv);
+                        *(uint2*)(orow + d) = w;
+                    }
                 }
-            }
+        }
     }
+}
+
+template <int DH, int QT>
+int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
+                       int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+    using Cfg = AttnCfg<DH>;
+    dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
+    const int lds = Cfg::K_BYTES + Cfg::V_BYTES;
+    static const bool prio = !(getenv("SDV_ATTN_PRIO") && atoi(getenv("SDV_ATTN_PRIO")) == 0);   // default on (+1..3 %)
+    if (prio)
+        hipLaunchKernelGGL((attention_kernel<DH, QT, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
+                           scale * 1.4426950408889634f);
+    else
+        hipLaunchKernelGGL((attention_kernel<DH, QT, false>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv,
+                           ldo, scale * 1.4426950408889634f);
+    SDV_CHECK_LAUNCH("sdv_attention_bf16");
+    return SDV_OK;
 }
 
 template <int DH>
 int launch_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
-    using Cfg = AttnCfg<DH>;
-    dim3 grid((Lq + 127) / 128, H, B);
-    const int lds = Cfg::K_BYTES + Cfg::V_BYTES;
-    static const bool prio = getenv("SDV_ATTN_PRIO") && atoi(getenv("SDV_ATTN_PRIO")) != 0;   // experiment knob
-    if (prio)
-        hipLaunchKernelGGL((attention_kernel<DH, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
-                           scale * 1.4426950408889634f);
-    else
-        hipLaunchKernelGGL((attention_kernel<DH, false>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
-                           scale * 1.4426950408889634f);
-    SDV_CHECK_LAUNCH("sdv_attention_bf16");
-    return SDV_OK;
+    // 64 queries per wave halve the LDS fragment traffic and the barriers per MFMA; only worth it (and only
+    // compiled) for the narrow heads and long sequences, where it fits the register file at 2 waves / SIMD.
+    static const int qt_env = getenv("SDV_ATTN_QT") ? atoi(getenv("SDV_ATTN_QT")) : 0;   // experiment knob
+    if constexpr (DH <= 64) {
+        const bool two = qt_env ? qt_env == 2 : false;
+        if (two && Lq >= 1024) return launch_attention_q<DH, 2>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+    }
+    return launch_attention_q<DH, 1>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
 }
 
 // ---- in-place row softmax over bf16 (VAE mid-block attention scores) -------------------------
