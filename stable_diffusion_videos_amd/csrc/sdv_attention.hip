@@ -41,7 +41,7 @@ struct AttnCfg {
     static constexpr int VPT = (VCH + 255) / 256;
 };
 
-template <int DH, int QT, bool PRIO>
+template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -49,7 +49,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     // QT = 32-query tiles per wave: the K / V^T fragments read from LDS are reused for QT MFMAs each.
     using Cfg = AttnCfg<DH>;
     constexpr int DKS = Cfg::DKS, DVT = Cfg::DVT, KROW = Cfg::KROW, VROW = Cfg::VROW;
+    // LEAN softmax - the dh = 40 / 80 kernels are VALU-issue-bound, not MFMA-bound (~150 VALU per 14 MFMAs at dh = 40):
+    //  * Q is pre-multiplied by scale*log2(e) when its fragments are loaded, so scores come out of the MFMA in log2 units;
+    //  * ONES (dh % 32 != 0, the V^T tile has padding rows): rows DH and DH+4 of the V^T tile hold 1.0, so the PV MFMA
+    //    itself accumulates the row sum l = sum_k P into accumulator register ONES_R of the last d-tile of every lane -
+    //    no per-score add, and l is rescaled together with O;
+    //  * PADM (dh % 16 == 8, the K tile has padding columns): K column DH holds 1.0 and Q' column DH holds -m_ref (the
+    //    running max, kept bf16-representable), so the MFMA delivers S' = K.Q'^T - m_ref and P = exp2(S') needs no
+    //    per-score subtract either.
+    constexpr bool ONES = LEAN && (DH % 32 != 0);
+    constexpr int ONES_R = 4 * ((DH % 32) / 8);
+    constexpr bool PADM = LEAN && (DH % 16 == 8);
+    constexpr int PADM_KS = DH / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // DBUF: two K / V^T tile buffers, tile t+1 is written while tile t is consumed -> ONE barrier per tile
+    constexpr int KV_BYTES = Cfg::K_BYTES + Cfg::V_BYTES;
+    constexpr int NBUF = DBUF ? 2 : 1;
     char* ldsK = smem;
     char* ldsV = smem + Cfg::K_BYTES;
 
@@ -63,7 +78,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int q0 = (blockIdx.x * 4 + wave) * (32 * QT);
 
     // zero the LDS pads once: K columns [DH, DKP) and V^T rows [DH, DVP) are never rewritten
-    for (int i = tid; i < (Cfg::K_BYTES + Cfg::V_BYTES) / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < NBUF * KV_BYTES / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    if constexpr (ONES) {
+        __syncthreads();
+        for (int bf = 0; bf < NBUF; ++bf) {
+            if (tid < 16)   // rows DH (lanes 0-31 hold it in acc register ONES_R) and DH + 4 (lanes 32-63), 64 keys each
+                *(uint4*)(ldsV + bf * KV_BYTES + (DH + 4 * (tid >> 3)) * VROW + (tid & 7) * 16) =
+                    make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+            if constexpr (PADM)
+                if (tid < 64) *(uint16_t*)(ldsK + bf * KV_BYTES + tid * KROW + DH * 2) = 0x3F80;   // K[key][DH] = 1.0
+        }
+    }
 
     // ---- Q fragments (B operand): lane owns query rows q0 + qt*32 + l31, d = ks*16 + lhi*8 .. +7 ----
     bf16x8_t qf[QT][DKS];
@@ -75,10 +100,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
         for (int ks = 0; ks < DKS; ++ks) {
             const int d0 = ks * 16 + lhi * 8;
-            if (d0 < DH)
-                qf[qt][ks] = *(const bf16x8_t*)(qrow + d0);
-            else
+            if (d0 < DH) {
+                if constexpr (LEAN) {
+                    const u32x4_t raw = *(const u32x4_t*)(qrow + d0);
+                    u32x4_t sc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sc[e] = pack_bf16x2(__builtin_bit_cast(float, raw[e] << 16) * scale_log2e,
+                                            __builtin_bit_cast(float, raw[e] & 0xFFFF0000u) * scale_log2e);
+                    qf[qt][ks] = __builtin_bit_cast(bf16x8_t, sc);
+                } else {
+                    qf[qt][ks] = *(const bf16x8_t*)(qrow + d0);
+                }
+            } else {
                 qf[qt][ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     }
 
@@ -106,13 +142,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             vreg[i] = *(const u32x4_t*)(Vb + (long long)row * ldv + kv0 + cc * 8);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int boff) {
 #pragma unroll
         for (int i = 0; i < Cfg::KPT; ++i) {
             int c = tid + i * 256;
             c = c < Cfg::KCH ? c : Cfg::KCH - 1;
             const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
-            *(u32x4_t*)(ldsK + row * KROW + cc * 16) = kreg[i];
+            *(u32x4_t*)(ldsK + boff + row * KROW + cc * 16) = kreg[i];
         }
         // V^T row d holds 64 keys; within each 16-key block the 4-key groups are stored in the order
         // [0-3][8-11][4-7][12-15] so that one ds_read_b128 at (block*16 + lhi*8) keys yields exactly
@@ -122,7 +158,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             int c = tid + i * 256;
             c = c < Cfg::VCH ? c : Cfg::VCH - 1;
             const int row = c >> 3, cc = c & 7;  // cc: 8-key chunk; block = cc>>1, half = cc&1
-            char* dst = ldsV + row * VROW + (cc >> 1) * 32 + (cc & 1) * 8;
+            char* dst = ldsV + boff + row * VROW + (cc >> 1) * 32 + (cc & 1) * 8;
             *(u32x2_t*)(dst) = u32x2_t{vreg[i][0], vreg[i][1]};        // keys +0..3
             *(u32x2_t*)(dst + 16) = u32x2_t{vreg[i][2], vreg[i][3]};   // keys +4..7
         }
@@ -132,7 +168,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     float m_run[QT], l_run[QT];  // l_run: this lane's partial row sum (its 32 of the 64 keys per tile)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        m_run[qt] = -INFINITY;
+        m_run[qt] = PADM ? 0.f : -INFINITY;   // PADM: m_ref, what Q' column DH currently subtracts
         l_run[qt] = 0.f;
 #pragma unroll
         for (int t = 0; t < DVT; ++t)
@@ -142,11 +178,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 
     const int ntiles = (Lk + 63) / 64;
     load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();  // previous tile fully consumed (and the pad zeroing is visible)
-        store_tile();
+    if constexpr (DBUF) {
+        __syncthreads();   // pad initialisation visible / ordered before the first tile lands
+        store_tile(0);
+        if (ntiles > 1) load_tile(64);
         __syncthreads();
-        if (t + 1 < ntiles) load_tile((t + 1) * 64);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        int boff = 0;
+        if constexpr (DBUF) {
+            boff = (t & 1) * KV_BYTES;
+            if (t + 1 < ntiles) {
+                store_tile(KV_BYTES - boff);          // tile t+1 -> the buffer tile t-1 was read from (barrier below)
+                if (t + 2 < ntiles) load_tile((t + 2) * 64);
+            }
+        } else {
+            __syncthreads();  // previous tile fully consumed (and the pad zeroing is visible)
+            store_tile(0);
+            __syncthreads();
+            if (t + 1 < ntiles) load_tile((t + 1) * 64);
+        }
 
         // ---- S^T = K . Q^T for two 32-key subtiles (each K fragment feeds QT MFMAs) ----
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);   // matrix-pipe clusters win issue arbitration (guide T5)
@@ -155,7 +206,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int ks = 0; ks < DKS; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(ldsK + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
+                const bf16x8_t kf = *(const bf16x8_t*)(ldsK + boff + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     if (ks == 0)
@@ -186,18 +237,55 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qt][0][r]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qt][1][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;      // scale > 0: max commutes with it
-            // deferred rescale: keep the old running max while the tile max grows by < kDefer (P stays <= 2^kDefer,
-            // exact in fp32 accumulation); when it fires, O and l are rescaled BEFORE this tile's P exists.
-            if (!__all(mx - m_run[qt] <= kDefer)) {
-                const float m_new = fmaxf(m_run[qt], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-                m_run[qt] = m_new;
-                l_run[qt] *= alpha;
+            if constexpr (PADM) {
+                // scores arrive relative to m_ref (0 before the first tile, which is forced to set it): mx is how far
+                // this tile rises above it.  m_ref stays bf16-representable so that Q' column DH holds it exactly.
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (t == 0 || !__all(mx <= kDefer)) {
+                    const float want = m_run[qt] + (t == 0 ? mx : fmaxf(mx, 0.f));
+                    const uint32_t mbits = pack_bf16x2(want, 0.f) << 16;
+                    const float m_new = __builtin_bit_cast(float, mbits);
+                    const float delta = m_new - m_run[qt];
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    m_run[qt] = m_new;
+                    u32x4_t qw = __builtin_bit_cast(u32x4_t, qf[qt][PADM_KS]);
+                    qw[0] = lhi ? ((mbits ^ 0x80000000u) >> 16) : qw[0];           // element DH of Q' = -m_ref
+                    qf[qt][PADM_KS] = __builtin_bit_cast(bf16x8_t, qw);
 #pragma unroll
-                for (int dt = 0; dt < DVT; ++dt)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
+                        for (int r = 0; r < 16; ++r) s[qt][j][r] -= delta;
+#pragma unroll
+                    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
+                }
+            } else if constexpr (LEAN) {
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (!__all(mx - m_run[qt] <= kDefer)) {
+                    const float m_new = fmaxf(m_run[qt], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                    m_run[qt] = m_new;
+                    if constexpr (!ONES) l_run[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
+                }
+            } else {
+                mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;      // scale > 0: max commutes with it
+                // deferred rescale: keep the old running max while the tile max grows by < kDefer (P stays <= 2^kDefer,
+                // exact in fp32 accumulation); when it fires, O and l are rescaled BEFORE this tile's P exists.
+                if (!__all(mx - m_run[qt] <= kDefer)) {
+                    const float m_new = fmaxf(m_run[qt], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                    m_run[qt] = m_new;
+                    l_run[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
+                }
             }
             float psum = 0.f;
 #pragma unroll
@@ -207,8 +295,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                     float pv[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][j][8 * u + e], scale_log2e, -m_run[qt]));
-                        psum += pv[e];
+                        if constexpr (PADM)
+                            pv[e] = __builtin_amdgcn_exp2f(s[qt][j][8 * u + e]);
+                        else if constexpr (LEAN)
+                            pv[e] = __builtin_amdgcn_exp2f(s[qt][j][8 * u + e] - m_run[qt]);
+                        else
+                            pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][j][8 * u + e], scale_log2e, -m_run[qt]));
+                        if constexpr (!ONES) psum += pv[e];
                     }
                     u32x4_t pr;
                     pr[0] = pack_bf16x2(pv[0], pv[1]);
@@ -217,7 +310,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                     pr[3] = pack_bf16x2(pv[6], pv[7]);
                     pf[qt][j * 2 + u] = __builtin_bit_cast(bf16x8_t, pr);
                 }
-            l_run[qt] += psum;
+            if constexpr (!ONES) l_run[qt] += psum;
         }
         // ---- O^T += V^T . P^T (each V^T fragment feeds QT MFMAs) ----
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
@@ -225,18 +318,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
             for (int ju = 0; ju < 4; ++ju) {
-                const bf16x8_t vf = *(const bf16x8_t*)(ldsV + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
+                const bf16x8_t vf = *(const bf16x8_t*)(ldsV + boff + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt][ju], o[qt][dt], 0, 0, 0);
             }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+        if constexpr (DBUF) __syncthreads();   // tile t+1 visible; everyone is done reading tile t's buffer
     }
 
     // ---- normalise and store O[q][h*DH + d] ----
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+        float l_tot;
+        if constexpr (ONES)
+            l_tot = o[qt][DVT - 1][ONES_R];
+        else
+            l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
         const float inv = 1.0f / l_tot;
         const int q = q0 + qt * 32 + l31;
         if (q < Lq) {
@@ -262,14 +360,23 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
                        int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
     using Cfg = AttnCfg<DH>;
     dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
-    const int lds = Cfg::K_BYTES + Cfg::V_BYTES;
+    // experiment knob, default OFF: one barrier per tile measured -4 % at dh = 40 (8 more VGPRs -> 3 waves / SIMD) and
+    // +-0 at dh = 80; the two barriers are not what limits this kernel.
+    static const bool dbuf_env = getenv("SDV_ATTN_DBUF") && atoi(getenv("SDV_ATTN_DBUF")) != 0;
+    const bool dbuf = dbuf_env && DH <= 80;   // dh = 160: two buffers would cost a resident workgroup (2 x 89 KB > 160 KB)
+    const int lds = (Cfg::K_BYTES + Cfg::V_BYTES) * (dbuf ? 2 : 1);
     static const bool prio = !(getenv("SDV_ATTN_PRIO") && atoi(getenv("SDV_ATTN_PRIO")) == 0);   // default on (+1..3 %)
-    if (prio)
-        hipLaunchKernelGGL((attention_kernel<DH, QT, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo,
-                           scale * 1.4426950408889634f);
-    else
-        hipLaunchKernelGGL((attention_kernel<DH, QT, false>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv,
-                           ldo, scale * 1.4426950408889634f);
+    static const bool lean_env = !(getenv("SDV_ATTN_LEAN") && atoi(getenv("SDV_ATTN_LEAN")) == 0);
+    const bool lean = lean_env && (DH % 32 != 0);   // dh = 64 / 160 have no padding rows or columns to exploit
+    const float sl = scale * 1.4426950408889634f;
+#define SDV_ATTN_LAUNCH(P, L, D) \
+    hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl)
+    if (!prio) SDV_ATTN_LAUNCH(false, false, false);      // reference variant kept for A/B runs (SDV_ATTN_PRIO=0)
+    else if (lean && dbuf) SDV_ATTN_LAUNCH(true, true, true);
+    else if (lean) SDV_ATTN_LAUNCH(true, true, false);
+    else if (dbuf) SDV_ATTN_LAUNCH(true, false, true);
+    else SDV_ATTN_LAUNCH(true, false, false);
+#undef SDV_ATTN_LAUNCH
     SDV_CHECK_LAUNCH("sdv_attention_bf16");
     return SDV_OK;
 }
