@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): interpolated frames/sec, 512x512, 50 DDIM steps.  Workload at N=1 = BASELINE config[1]:
-SD-v1-4 architecture, bf16, 2 prompts, walk of K*B interpolated frames (default 2 x 32 = 64), CFG 7.5, eta 0.
+SD-v1-4 architecture, bf16, 2 prompts, walk of K*B interpolated frames (default 2 x 64 = 128), CFG 7.5, eta 0.
 A "step" is one pass of the hot path over one batch of B frames: lerp(text embeddings) + slerp(noise) for the
 batch -> 50 x (UNet on 2B samples + fused CFG/DDIM update), each a hipGraph replay -> VAE decode -> uint8 frames
 copied to the host.  Endpoint embeddings / endpoint noise are resident in HBM before the timed region; PNG
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("SDV_BENCH_BATCH", "32")))
+    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("SDV_BENCH_BATCH", "64")))
     ap.add_argument("--arch", default="sd14", choices=["sd14", "sd21", "tiny"])
     ap.add_argument("--size", type=int, default=0, help="image size (default: 512 for sd14, 768 for sd21)")
     ap.add_argument("--inference-steps", type=int, default=50)
