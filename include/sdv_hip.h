@@ -53,6 +53,7 @@ int sdv_abi_version(void);
  * epi       0: bf16 out = acc*alpha (+bias) (+R)      [ldc, residual R with ldr]
  *           1: GEGLU: W rows pre-interleaved per 32-row tile as [16 value | 16 gate]; out is [M][N/2]
  *           2: as 0, then SiLU
+ *           3: as 0, then LeakyReLU(0.2)   (RRDBNet convs of the Real-ESRGAN upsampler, upsampling.py:25)
  * bias      fp32; bias_mode 1 = per n, 2 = per m.  If step_ptr != NULL the bias row used is
  *           bias + (*step_ptr) * bias_step_stride (per-denoise-step time-embedding bias table).
  * zero_page unused since ABI v1 kernels zero-fill padding through the buffer-descriptor range check (may be NULL).
@@ -73,7 +74,7 @@ typedef struct sdv_gemm_args {
     int32_t mode, Hin, Win, Hout, Wout, circular;
     int32_t epi, bias_mode, bias_step_stride;
     int32_t batch;
-    int32_t tile;    /* 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves) */
+    int32_t tile;    /* 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 256x32, 11 = 256x64 (4 waves) */
     float alpha;
 } sdv_gemm_args;
 
@@ -121,6 +122,8 @@ int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta,
  *     out_mode 1: image epilogue of stable_diffusion_pipeline.py:435-438 + numpy_to_pil (:450):
  *                 img = clamp(v/2+0.5, 0, 1) -> out_f32 (optional, fp32 NHWC) and
  *                 out_u8 = rint(img*255) (round-half-even) uint8 NHWC
+ *     out_mode 2: as 1 with img = clamp(v, 0, 1): RealESRGANer.enhance post-processing (clamp_(0,1), (x*255).round()),
+ *                 reached from upsampling.py:46
  * ------------------------------------------------------------------------------------------ */
 int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Cin]*/, const float* bias,
                           sdv_bf16* Y, int32_t nimg, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
@@ -179,6 +182,14 @@ int sdv_linear_small(const float* x, const sdv_bf16* w, const float* b, const fl
 int sdv_nchw_to_nhwc_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream);
 int sdv_nhwc_to_nchw_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream);
 int sdv_f32_to_bf16(const float* in, sdv_bf16* out, int64_t n, void* stream);
+
+/* Real-ESRGAN x4 upsampler (upsampling.py:25-28, :46: RRDBNet inside RealESRGANer.enhance) - the glue around
+ * sdv_gemm_bf16 / sdv_im2col3x3_c4 / sdv_conv3x3_cout_small:
+ *   rgb_u8_to_bf16_c4: uint8 RGB NHWC pixels -> 4-channel bf16 rows {r,g,b,0}*scale (pre_process: img/255)
+ *   axpby_bf16:        out = alpha*a + beta*b over strided bf16 rows (RRDB: out*0.2 + x), cols/strides % 8 == 0 */
+int sdv_rgb_u8_to_bf16_c4(const uint8_t* in, sdv_bf16* out, int64_t npix, float scale, void* stream);
+int sdv_axpby_bf16(const sdv_bf16* a, int32_t lda, const sdv_bf16* b, int32_t ldb, sdv_bf16* out, int32_t ldo,
+                   int64_t rows, int32_t cols, float alpha, float beta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,17 @@ class VAEConfig:
 
 
 @dataclass
+class RRDBNetConfig:
+    """Real-ESRGAN x4plus generator (reference upsampling.py:25)."""
+    num_in_ch: int = 3
+    num_out_ch: int = 3
+    num_feat: int = 64
+    num_block: int = 23
+    num_grow_ch: int = 32
+    scale: int = 4
+
+
+@dataclass
 class TextConfig:
     vocab_size: int = 49408
     hidden_size: int = 768

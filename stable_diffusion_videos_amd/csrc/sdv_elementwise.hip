@@ -17,7 +17,7 @@ void sdv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sdv_last_error(void) { return g_err; }
-extern "C" int sdv_abi_version(void) { return 1; }
+extern "C" int sdv_abi_version(void) { return 2; }
 
 namespace {
 
@@ -215,6 +215,36 @@ __global__ __launch_bounds__(kThreads) void f32_to_bf16_kernel(const float* __re
         out[i] = f32_to_bf16(in[i]);
 }
 
+// uint8 RGB pixels -> 4-channel bf16 rows {r, g, b, 0} * scale  (RealESRGANer.pre_process: img / 255)
+__global__ __launch_bounds__(kThreads) void rgb_u8_to_bf16_c4_kernel(const uint8_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                                     long long npix, float scale) {
+    for (long long p = (long long)blockIdx.x * kThreads + threadIdx.x; p < npix; p += (long long)gridDim.x * kThreads) {
+        const uint8_t* px = in + p * 3;
+        uint2 o;
+        o.x = pack_bf16x2(px[0] * scale, px[1] * scale);
+        o.y = pack_bf16x2(px[2] * scale, 0.f);
+        *(uint2*)(out + p * 4) = o;
+    }
+}
+
+// out[r][c] = alpha * a[r][c] + beta * b[r][c] over strided bf16 rows (the 0.2-scaled residual sums of RRDBNet)
+__global__ __launch_bounds__(kThreads) void axpby_bf16_kernel(const uint16_t* __restrict__ a, int lda, const uint16_t* __restrict__ b,
+                                                              int ldb, uint16_t* __restrict__ out, int ldo, long long rows,
+                                                              int cols, float alpha, float beta) {
+    const int cpr = cols >> 3;
+    const long long n = rows * cpr;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const long long r = i / cpr;
+        const int c = (int)(i - r * cpr) * 8;
+        float fa[8], fb[8];
+        unpack8(*(const bf16x8_raw*)(a + r * lda + c), fa);
+        unpack8(*(const bf16x8_raw*)(b + r * ldb + c), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] = alpha * fa[e] + beta * fb[e];
+        *(bf16x8_raw*)(out + r * ldo + c) = pack8(fa);
+    }
+}
+
 // z[p][o] = sum_c Wpq[o][c] * (x[p][c] * in_scale) + b[o]      (C <= 8)
 __global__ __launch_bounds__(kThreads) void latent_affine_kernel(const float* __restrict__ X, const float* __restrict__ Wpq,
                                                                  const float* __restrict__ bias, float in_scale,
@@ -377,7 +407,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_cout_small_kernel(const uint
                 if (out_mode == 0) {
                     out_f32[pix * COUT + o] = v;
                 } else {
-                    v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);
+                    v = out_mode == 1 ? fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f) : fminf(fmaxf(v, 0.f), 1.f);
                     if (out_f32) out_f32[pix * COUT + o] = v;
                     if (out_u8) out_u8[pix * COUT + o] = (uint8_t)rintf(v * 255.0f);
                 }
@@ -486,6 +516,25 @@ extern "C" int sdv_f32_to_bf16(const float* in, sdv_bf16* out, int64_t n, void* 
     return SDV_OK;
 }
 
+extern "C" int sdv_rgb_u8_to_bf16_c4(const uint8_t* in, sdv_bf16* out, int64_t npix, float scale, void* stream) {
+    SDV_REQUIRE(in && out && npix > 0, "sdv_rgb_u8_to_bf16_c4: bad args");
+    hipLaunchKernelGGL(rgb_u8_to_bf16_c4_kernel, dim3(grid_for(npix)), dim3(kThreads), 0, (hipStream_t)stream, in, out,
+                       (long long)npix, scale);
+    SDV_CHECK_LAUNCH("sdv_rgb_u8_to_bf16_c4");
+    return SDV_OK;
+}
+
+extern "C" int sdv_axpby_bf16(const sdv_bf16* a, int32_t lda, const sdv_bf16* b, int32_t ldb, sdv_bf16* out, int32_t ldo,
+                              int64_t rows, int32_t cols, float alpha, float beta, void* stream) {
+    SDV_REQUIRE(a && b && out && rows > 0 && cols > 0, "sdv_axpby_bf16: bad args");
+    SDV_REQUIRE(cols % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "sdv_axpby_bf16: cols / strides must be multiples of 8");
+    SDV_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "sdv_axpby_bf16: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(axpby_bf16_kernel, dim3(grid_for(rows * (cols / 8))), dim3(kThreads), 0, (hipStream_t)stream, a, lda, b, ldb,
+                       out, ldo, (long long)rows, cols, alpha, beta);
+    SDV_CHECK_LAUNCH("sdv_axpby_bf16");
+    return SDV_OK;
+}
+
 extern "C" int sdv_latent_affine(const float* X, const float* Wpq, const float* bias, float in_scale, sdv_bf16* Y,
                                  int64_t npix, int32_t C, void* stream) {
     SDV_REQUIRE(X && Wpq && Y && npix > 0 && C > 0 && C <= 8, "sdv_latent_affine: bad args (C <= 8)");
@@ -542,6 +591,7 @@ extern "C" int sdv_conv3x3_cout_small(const sdv_bf16* X, const sdv_bf16* W, cons
     SDV_REQUIRE(X && W, "sdv_conv3x3_cout_small: null pointer");
     SDV_REQUIRE(Cout >= 1 && Cout <= 4, "sdv_conv3x3_cout_small: Cout must be 1..4 (got %d)", Cout);
     SDV_REQUIRE(Cin % 8 == 0 && Cin > 0, "sdv_conv3x3_cout_small: Cin must be a multiple of 8");
+    SDV_REQUIRE(out_mode >= 0 && out_mode <= 2, "sdv_conv3x3_cout_small: bad out_mode %d", out_mode);
     SDV_REQUIRE(out_mode == 0 ? out_f32 != nullptr : (out_f32 || out_u8), "sdv_conv3x3_cout_small: no output buffer");
     const size_t lds = (size_t)Cout * 9 * Cin * 2;
     SDV_REQUIRE(lds <= 64 * 1024, "sdv_conv3x3_cout_small: weights do not fit LDS");

@@ -376,6 +376,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                         if (p.epi == 2) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+                        } else if (p.epi == 3) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = lrelu02_f(f[e]);
                         }
                         *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
                     }
@@ -460,6 +463,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                     if (p.epi == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    } else if (p.epi == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = lrelu02_f(v[e]);
                     }
                     uint2 o;
                     o.x = pack_bf16x2(v[0], v[1]);
@@ -472,6 +478,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                         float t = v[e];
                         if (R) t += bf16_to_f32(R[(long long)m * p.ldr + nb + e]);
                         if (p.epi == 2) t = silu_f(t);
+                        if (p.epi == 3) t = lrelu02_f(t);
                         C[(long long)m * p.ldc + nb + e] = f32_to_bf16(t);
                     }
                 }
@@ -514,6 +521,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SDV_REQUIRE(a.K % 64 == 0, "sdv_gemm_bf16: K=%d must be a multiple of 64", a.K);
     SDV_REQUIRE(a.mode >= 0 && a.mode <= 3, "sdv_gemm_bf16: bad mode %d", a.mode);
+    SDV_REQUIRE(a.epi >= 0 && a.epi <= 3, "sdv_gemm_bf16: bad epi %d", a.epi);
     if (!a.X2) {
         a.C1 = a.K;
         a.ldx2 = a.ldx;
@@ -556,6 +564,8 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         struct Cand { int id, bm, bn; float rate; };
         static const Cand cands[] = {{6, 256, 320, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
                                      {1, 128, 128, 3.4f}, {2, 128, 64, 2.4f}, {3, 64, 64, 2.0f}};
+        // (the 4-wave 256x32 / 256x64 tiles 10 / 11 stay selectable but are not candidates: on the RRDBNet convs the
+        //  128x64 tile wins or ties everywhere - tools/esrgan_tile_sweep.py, profiles/round1_esrgan.txt)
         double best = 1e300;
         for (const Cand& c : cands) {
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
@@ -575,6 +585,8 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         case 7: return launch_igemm<4, 2, 2, 4, 64>(a, s);    // 256 x 256, 8 waves
         case 8: return launch_igemm<4, 2, 2, 2, 64>(a, s);    // 256 x 128, 8 waves
         case 9: return launch_igemm<4, 2, 1, 5, 64>(a, s);    // 128 x 320, 8 waves
+        case 10: return launch_igemm<4, 1, 2, 1, 64>(a, s);   // 256 x  32, 4 waves (RRDB growth convs, Cout = 32)
+        case 11: return launch_igemm<4, 1, 2, 2, 64>(a, s);   // 256 x  64, 4 waves
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
     return SDV_OK;

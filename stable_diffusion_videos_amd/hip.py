@@ -61,6 +61,9 @@ _SIGNATURES = {
     "sdv_nchw_to_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sdv_rgb_u8_to_bf16_c4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "sdv_axpby_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
+                                 C.c_float, C.c_float, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -190,9 +193,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, nimg: int, H: int, W: int,
             mode: int = 1, x2: Optional[torch.Tensor] = None, residual=None, circular: bool = False,
-            step_ptr=None, bias_step_stride: int = 0, out=None, tile: int = 0) -> torch.Tensor:
+            step_ptr=None, bias_step_stride: int = 0, out=None, tile: int = 0, epi: int = 0,
+            alpha: float = 1.0) -> torch.Tensor:
     """NHWC conv3x3 pad 1.  x: [nimg*H*W, C1] (+ x2 [.., C2]); w: [Cout, 9*(C1+C2)] (OHWI).
-    mode 1: stride 1; 2: stride 2; 3: nearest-2x upsample then conv."""
+    mode 1: stride 1; 2: stride 2; 3: nearest-2x upsample then conv.  x / out / residual may be column
+    slices of wider row-major buffers (row stride = .stride(0)): dense-block concat without copies."""
     C1 = x.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     Cout = w.shape[0]
@@ -210,7 +215,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
     gemm(x, w, out, M=M, N=Cout, K=C1 + C2, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
          residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2,
          C1=C1 if x2 is not None else 0, ldx2=x2.stride(0) if x2 is not None else 0, mode=mode, Hin=H, Win=W,
-         Hout=Ho, Wout=Wo, circular=circular, step_ptr=step_ptr, bias_step_stride=bias_step_stride, tile=tile)
+         Hout=Ho, Wout=Wo, circular=circular, step_ptr=step_ptr, bias_step_stride=bias_step_stride, tile=tile,
+         epi=epi, alpha=alpha)
     return out
 
 
@@ -288,7 +294,7 @@ def conv3x3_cin_small(x, w, bias, *, nimg, H, W, circular=False, out=None):
     return out
 
 
-def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False):
+def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False, out=None):
     """3x3 pad-1 conv of a 4-channel NHWC tensor on the matrix cores: im2col to 64-wide rows + K = 64 GEMM.
     ``w_pad``: [Cout, 64] = OHWI weights [Cout, 36] zero-padded (see ``weights.conv_w_c4``)."""
     lib = load()
@@ -298,7 +304,34 @@ def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False):
     xp, cp = _ptr(x, BF16, "X"), _ptr(cols, BF16)
     _launch("im2col_c4", dict(bytes=2.0 * nimg * H * W * (4 + 64)),
             lambda: _check(lib.sdv_im2col3x3_c4(xp, cp, nimg, H, W, int(circular), _stream()), "sdv_im2col3x3_c4"))
-    return linear(cols, w_pad, bias)
+    return linear(cols, w_pad, bias, out=out)
+
+
+def rgb_u8_to_bf16_c4(img_u8: torch.Tensor, scale: float = 1.0 / 255.0) -> torch.Tensor:
+    """uint8 RGB NHWC [..., 3] -> bf16 rows [npix, 4] = {r, g, b, 0} * scale."""
+    lib = load()
+    if img_u8.shape[-1] != 3 or not img_u8.is_contiguous():
+        raise SdvHipError("rgb_u8_to_bf16_c4: expected a contiguous [..., 3] uint8 tensor")
+    npix = img_u8.numel() // 3
+    out = torch.empty((npix, 4), dtype=BF16, device=img_u8.device)
+    _check(lib.sdv_rgb_u8_to_bf16_c4(_ptr(img_u8, torch.uint8, "img"), _ptr(out, BF16), npix, scale, _stream()),
+           "sdv_rgb_u8_to_bf16_c4")
+    return out
+
+
+def axpby(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float, beta: float):
+    """out = alpha*a + beta*b over [rows, cols] bf16 (column slices of wider buffers allowed)."""
+    lib = load()
+    rows, cols = a.shape
+    if b.shape != a.shape or out.shape != a.shape:
+        raise SdvHipError("axpby: shape mismatch")
+    for t in (a, b, out):
+        if t.stride(1) != 1:
+            raise SdvHipError("axpby: rows must be contiguous")
+    _launch("axpby", dict(bytes=6.0 * rows * cols),
+            lambda: _check(lib.sdv_axpby_bf16(_ptr(a, BF16, "a"), a.stride(0), _ptr(b, BF16, "b"), b.stride(0),
+                                              _ptr(out, BF16, "out"), out.stride(0), rows, cols, alpha, beta, _stream()),
+                           "sdv_axpby_bf16"))
 
 
 def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_u8=None, circular=False):

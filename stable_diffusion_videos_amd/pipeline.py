@@ -386,9 +386,12 @@ class StableDiffusionWalkPipeline:
                 callback(i, int(self.scheduler.timesteps[i]), hip.nhwc_to_nchw(ent["latents"]))
         if kwargs.get("return_latents", False):
             return hip.nhwc_to_nchw(ent["latents"])
-        want_float = output_type not in ("pil", "numpy_u8")       # "numpy_u8": rounded uint8 NHWC array, no PIL objects
+        # "numpy_u8": rounded uint8 NHWC array, no PIL objects; "u8_cuda": the same array left in HBM (upsampler input)
+        want_float = output_type not in ("pil", "numpy_u8", "u8_cuda")
         u8, f32 = self.vae.decode(ent["latents"], want_float=want_float)                         # :432-435
-        if want_float:
+        if output_type == "u8_cuda":
+            image = u8
+        elif want_float:
             image = f32.cpu().numpy()                                                             # :438
         else:
             image = u8.cpu().numpy()
@@ -467,10 +470,14 @@ class StableDiffusionWalkPipeline:
             logger.info(f"{log_prefix}[{batch_idx}/{num_batches}] {msg}")
             outputs = self(latents=noise_batch, text_embeddings=embeds_batch, height=height, width=width,
                            guidance_scale=guidance_scale, eta=eta, num_inference_steps=num_inference_steps,
-                           output_type="pil" if not upsample else "numpy", negative_prompt=negative_prompt)["images"]
+                           output_type="pil" if not upsample else "u8_cuda", negative_prompt=negative_prompt)["images"]
+            if upsample:
+                # :552 - the reference upsamples frame by frame on the way to disk (float -> uint8 -> RealESRGANer); here the
+                # uint8 frames never leave HBM before the x4 network has run on the whole batch
+                outputs = numpy_to_pil(self.upsampler.upsample_u8(outputs).cpu().numpy())
             for image in outputs:
                 frame_filepath = save_path / (f"frame%06d{image_file_ext}" % frame_index)
-                writer.submit(image, frame_filepath, self.upsampler if upsample else None)      # :552-553
+                writer.submit(image, frame_filepath)                                             # :553
                 frame_index += 1
         if self._writer is None:
             writer.close()

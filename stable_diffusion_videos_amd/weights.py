@@ -13,7 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .config import UNetConfig, VAEConfig
+from .config import RRDBNetConfig, UNetConfig, VAEConfig
 
 StateDict = Dict[str, torch.Tensor]
 
@@ -136,6 +136,40 @@ def vae_decoder_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
     return sd
 
 
+def rrdbnet_shapes(cfg: RRDBNetConfig) -> "OrderedDict[str, tuple]":
+    """basicsr ``RRDBNet`` state-dict schema (the ``params_ema`` / ``params`` dict of RealESRGAN_x4plus.pth)."""
+    sd: "OrderedDict[str, tuple]" = OrderedDict()
+    nf, g = cfg.num_feat, cfg.num_grow_ch
+    _conv(sd, "conv_first", cfg.num_in_ch, nf, 3)
+    for i in range(cfg.num_block):
+        for r in (1, 2, 3):
+            for k in range(1, 6):
+                _conv(sd, f"body.{i}.rdb{r}.conv{k}", nf + (k - 1) * g, g if k < 5 else nf, 3)
+    for name in ("conv_body", "conv_up1", "conv_up2", "conv_hr"):
+        _conv(sd, name, nf, nf, 3)
+    _conv(sd, "conv_last", nf, cfg.num_out_ch, 3)
+    return sd
+
+
+def load_rrdbnet(path, shapes) -> StateDict:
+    """RealESRGAN_x4plus.pth layout: ``{"params_ema": state_dict}`` (or ``params``, or the bare state dict)."""
+    raw = _load_file(Path(path))
+    for key in ("params_ema", "params"):
+        if key in raw and isinstance(raw[key], dict):
+            raw = raw[key]
+            break
+    missing = [k for k in shapes if k not in raw]
+    if missing:
+        raise KeyError(f"{path}: missing keys, e.g. {missing[:4]}")
+    out: StateDict = OrderedDict()
+    for k, shape in shapes.items():
+        t = raw[k].float()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{k}: shape {tuple(t.shape)} != expected {shape}")
+        out[k] = t
+    return out
+
+
 def count_params(shapes) -> int:
     return sum(math.prod(s) for s in shapes.values())
 
@@ -230,6 +264,17 @@ def conv_w_c4(w: torch.Tensor, device) -> torch.Tensor:
     out = torch.zeros((co, 64), dtype=flat.dtype)
     out[:, : flat.shape[1]] = flat
     return out.contiguous().to(device=device, dtype=torch.bfloat16)
+
+
+def conv_w_kpad(w: torch.Tensor, device, scale: float = 1.0) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> OHWI [Cout, 9*Kp] with Cin zero-padded to Kp = roundup(Cin, 64), the K granularity of
+    ``sdv_gemm_bf16`` (RRDB growth convs have Cin = 96 / 160: their padded channels read whatever the dense-block
+    buffer holds there - always finite - against zero weights)."""
+    co, ci = w.shape[:2]
+    kp = (ci + 63) // 64 * 64
+    out = torch.zeros((co, 3, 3, kp), dtype=torch.float32)
+    out[..., :ci] = w.permute(0, 2, 3, 1) * scale
+    return out.reshape(co, 9 * kp).contiguous().to(device=device, dtype=torch.bfloat16)
 
 
 def lin_w(w: torch.Tensor, device) -> torch.Tensor:

@@ -21,7 +21,7 @@ def test_c_abi_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libsdv_hip.so does not export {name}"
     assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip.load().sdv_abi_version() == 1
+    assert hip.load().sdv_abi_version() == 2
 
 
 def test_gemm_args_struct_matches_header(hip):
@@ -215,3 +215,41 @@ def test_local_checkpoint_directory_round_trip(tmp_path):
         assert torch.equal(pipe.vae.state_dict[k], v), k
     with pytest.raises(FileNotFoundError):
         weights.load_component(tmp_path, "text_encoder", {})
+
+
+def test_realesrgan_surface_and_weights(tmp_path):
+    """Host side of the Real-ESRGAN row (reference upsampling.py:13-99): constructor / method surface, the
+    RealESRGAN_x4plus.pth container layouts, the K-padded weight re-layout, and loud failure without a GPU."""
+    import inspect
+    from stable_diffusion_videos_amd.config import RRDBNetConfig
+    from stable_diffusion_videos_amd.upsampling import PipelineRealESRGAN, RealESRGANModel
+    from stable_diffusion_videos_amd.weights import (conv_w_kpad, count_params, load_rrdbnet, rrdbnet_shapes,
+                                                     synthetic_state_dict)
+    assert PipelineRealESRGAN is RealESRGANModel
+    assert list(inspect.signature(RealESRGANModel.__init__).parameters)[:6] == ["self", "model_path", "tile", "tile_pad",
+                                                                                "pre_pad", "fp32"]
+    assert list(inspect.signature(RealESRGANModel.forward).parameters) == ["self", "image", "outscale", "convert_to_pil"]
+    assert list(inspect.signature(RealESRGANModel.upsample_imagefolder).parameters) == [
+        "self", "in_dir", "out_dir", "suffix", "outfile_ext", "recursive", "force"]
+    shapes = rrdbnet_shapes(RRDBNetConfig())
+    assert count_params(shapes) == 16_697_987
+    small = rrdbnet_shapes(RRDBNetConfig(num_block=1))
+    sd = synthetic_state_dict(small, seed=3)
+    for container in ({"params_ema": sd}, {"params": sd}, sd):
+        f = tmp_path / "RealESRGAN_x4plus.pth"
+        torch.save(container, f)
+        back = load_rrdbnet(f, small)
+        assert all(torch.equal(back[k], sd[k]) for k in small)
+    with pytest.raises(KeyError):
+        load_rrdbnet(f, shapes)                                       # 1-block file against the 23-block schema
+    w = torch.randn(32, 96, 3, 3)
+    wk = conv_w_kpad(w, "cpu").float().reshape(32, 3, 3, 128)
+    assert torch.equal(wk[..., :96], w.permute(0, 2, 3, 1).to(torch.bfloat16).float()) and float(wk[..., 96:].abs().max()) == 0
+    m = RealESRGANModel.from_pretrained(str(tmp_path / "nowhere"))   # nothing found offline -> synthetic, flagged
+    assert m.synthetic and m.scale == 4
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.to("cpu")
+    with pytest.raises(NotImplementedError):
+        RealESRGANModel(None, tile=256)
+    with pytest.raises(FileNotFoundError):
+        m.upsample_imagefolder(tmp_path / "missing", tmp_path / "out")

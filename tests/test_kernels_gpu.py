@@ -24,7 +24,7 @@ def rnd(shape, dev, seed, scale=1.0):
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
-ALL_TILES = [1, 2, 3, 4, 6, 7, 8, 9]
+ALL_TILES = [1, 2, 3, 4, 6, 7, 8, 9, 10, 11]
 
 
 @pytest.mark.parametrize("tile", ALL_TILES)
@@ -122,7 +122,7 @@ def conv_ref(x_nhwc, w, bias, mode, circular):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 6, 9])
+@pytest.mark.parametrize("tile", [0, 1, 6, 9, 10, 11])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("circular", [False, True])
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320),
@@ -182,6 +182,68 @@ def test_conv_small_channel_kernels(hip, dev):
     u = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
     hip.conv3x3_cout_small(x.reshape(-1, 128).to(BF16), conv_w(w, dev), b, nimg=n, H=H, W=W, out_mode=1, out_f32=f, out_u8=u)
     ref = (conv_ref(x, w, b, 1, False) / 2 + 0.5).clamp(0, 1)
+    assert float((f - ref).abs().max()) < 1e-5
+    assert torch.equal(u.cpu(), torch.from_numpy((f.cpu().numpy() * 255).round().astype("uint8")))
+
+
+@pytest.mark.parametrize("tile", [0, 2, 3, 10, 11])
+def test_conv3x3_dense_block_forms(hip, dev, tile):
+    """The RRDBNet conv forms: input = a column prefix of a wider row-major buffer, output written into a column slice
+    of the SAME buffer (dense concat through ldx / ldc), LeakyReLU(0.2) epilogue, zero-padded K for Cin = 96, and
+    the scaled residual of conv5 (0.2 * (conv + b) + x)."""
+    from stable_diffusion_videos_amd.weights import conv_w_kpad
+    n, H, W, nf, g, ld = 2, 20, 12, 64, 32, 192
+    M = n * H * W
+    buf = rnd((M, ld), dev, 60)                                   # [x | x1 | junk ...] - junk must not leak into results
+    ref_in = buf[:, :nf + g].reshape(n, H, W, nf + g).clone()
+    w = rnd((g, nf + g, 3, 3), dev, 61, (9 * (nf + g)) ** -0.5)
+    b = rnd((g,), dev, 62)
+    ref = F.leaky_relu(conv_ref(ref_in, w, b, 1, False), 0.2).reshape(M, g)
+    wk = conv_w_kpad(w.cpu(), dev)
+    assert wk.shape == (g, 9 * 128)
+    bb = buf.to(BF16)
+    keep = bb.clone()
+    hip.conv3x3(bb[:, :128], wk, b, nimg=n, H=H, W=W, out=bb[:, nf + g:nf + 2 * g], epi=3, tile=tile)
+    torch.cuda.synchronize()
+    assert rel_l2(bb[:, nf + g:nf + 2 * g].float(), ref) < MFMA_TOL
+    assert torch.equal(bb[:, :nf + g], keep[:, :nf + g]) and torch.equal(bb[:, nf + 2 * g:], keep[:, nf + 2 * g:])
+    # conv5 form: all 192 columns in, 64 out into another buffer, residual = x, alpha = 0.2 with pre-scaled bias
+    w5 = rnd((nf, ld, 3, 3), dev, 63, (9 * ld) ** -0.5)
+    b5 = rnd((nf,), dev, 64)
+    src = rnd((M, ld), dev, 65)
+    ref5 = 0.2 * conv_ref(src.reshape(n, H, W, ld), w5, b5, 1, False).reshape(M, nf) + src[:, :nf]
+    dst = torch.zeros((M, ld), dtype=BF16, device=dev)
+    sb = src.to(BF16)
+    hip.conv3x3(sb, conv_w_kpad(w5.cpu(), dev), b5 * 0.2, nimg=n, H=H, W=W, out=dst[:, :nf], residual=sb[:, :nf], alpha=0.2,
+                tile=tile)
+    torch.cuda.synchronize()
+    assert rel_l2(dst[:, :nf].float(), ref5) < MFMA_TOL
+    assert float(dst[:, nf:].float().abs().max()) == 0.0
+
+
+def test_esrgan_glue_kernels(hip, dev):
+    g = torch.Generator().manual_seed(70)
+    img = torch.randint(0, 256, (2, 9, 7, 3), generator=g, dtype=torch.uint8).to(dev)
+    x4 = hip.rgb_u8_to_bf16_c4(img)
+    ref = torch.zeros((2 * 9 * 7, 4))
+    ref[:, :3] = img.cpu().reshape(-1, 3).float() / 255.0
+    assert torch.equal(x4.cpu().float(), bf16_round(ref))
+    a, b = rnd((50, 192), dev, 71).to(BF16), rnd((50, 64), dev, 72).to(BF16)
+    out = torch.zeros((50, 128), dtype=BF16, device=dev)
+    hip.axpby(a[:, 64:128], b, out[:, 32:96], 0.2, 1.0)
+    torch.cuda.synchronize()
+    exp = bf16_round(0.2 * a[:, 64:128].float() + b.float())
+    assert float((out[:, 32:96].float() - exp).abs().max()) <= 1e-6 + float(exp.abs().max()) * 2 ** -8
+    assert float(out[:, :32].float().abs().max()) == 0.0 and float(out[:, 96:].float().abs().max()) == 0.0
+    hip.axpby(out[:, 32:96], b, b, 0.0, 1.0)                       # in place, identity
+    # conv_last form: 64 -> 3 with clamp(v, 0, 1) -> uint8 (RealESRGANer post-processing)
+    from stable_diffusion_videos_amd.weights import conv_w
+    n, H, W = 2, 10, 12
+    x, w, bias = rnd((n, H, W, 64), dev, 73), rnd((3, 64, 3, 3), dev, 74, 2 * (9 * 64) ** -0.5), rnd((3,), dev, 75) + 0.5
+    f = torch.empty((n, H, W, 3), dtype=F32, device=dev)
+    u = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    hip.conv3x3_cout_small(x.reshape(-1, 64).to(BF16), conv_w(w, dev), bias, nimg=n, H=H, W=W, out_mode=2, out_f32=f, out_u8=u)
+    ref = conv_ref(x, w, bias, 1, False).clamp(0, 1)
     assert float((f - ref).abs().max()) < 1e-5
     assert torch.equal(u.cpu(), torch.from_numpy((f.cpu().numpy() * 255).round().astype("uint8")))
 

@@ -337,3 +337,81 @@ def test_walk_with_audio_and_video(hip, dev, tmp_path):
         assert (clip / f"audio_{i:06d}.mp4").exists()
     cfg = json.loads((root / "prompt_config.json").read_text())
     assert cfg["audio_filepath"] == str(wav) and cfg["audio_start_sec"] == 2 and cfg["num_interpolation_steps"] == steps
+
+
+# ------------------------------------------------------------------------------------------------
+# Real-ESRGAN x4: RRDBNet on the HIP kernels vs the fp32 oracle restatement
+# ------------------------------------------------------------------------------------------------
+def _esrgan_pair(dev, num_block, probe, seed=0):
+    """Engine + oracle on the same bf16-exact synthetic weights.  Random weights make the un-normalised generator's
+    output far wider than [0, 1] (everything would clamp and the comparison would be vacuous), so conv_last is scaled by
+    a power of two (exact in bf16) that brings the oracle's output on ``probe`` to a standard deviation of ~0.15 around
+    0.5."""
+    import math
+    from oracle.esrgan import RRDBNet, RRDBNetConfig as OCfg
+    from stable_diffusion_videos_amd.config import RRDBNetConfig
+    from stable_diffusion_videos_amd.esrgan import RRDBNetEngine
+    from stable_diffusion_videos_amd.weights import rrdbnet_shapes, synthetic_state_dict
+    cfg = RRDBNetConfig(num_block=num_block)
+    sd = synthetic_state_dict(rrdbnet_shapes(cfg), seed=seed)
+    sd["conv_last.bias"] = torch.full_like(sd["conv_last.bias"], 0.5)
+    oracle = RRDBNet(OCfg(num_block=num_block)).eval()
+    oracle.load_state_dict(sd)
+    with torch.no_grad():
+        std = float((oracle(probe) - 0.5).std())
+    sd["conv_last.weight"] = sd["conv_last.weight"] * 2.0 ** math.floor(math.log2(0.15 / std))
+    oracle.load_state_dict(sd)
+    return RRDBNetEngine(cfg, sd, dev), oracle
+
+
+@pytest.mark.parametrize("num_block,n,H,W", [(2, 2, 24, 40), (23, 1, 64, 64)])
+def test_esrgan_matches_oracle(hip, dev, num_block, n, H, W):
+    """Stated tolerance: PSNR >= 35 dB on the clamped [0,1] output (bf16 storage through up to 345 convs vs fp32),
+    uint8 frames within a few grey levels.  **parity unpinned** (oracle/esrgan.py)."""
+    from oracle.esrgan import enhance_rgb_u8
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (n, H, W, 3), generator=g, dtype=torch.uint8)
+    engine, oracle = _esrgan_pair(dev, num_block, img.float().div(255).permute(0, 3, 1, 2))
+    u8, f32 = engine(img.to(dev), want_float=True)
+    torch.cuda.synchronize()
+    assert u8.shape == (n, 4 * H, 4 * W, 3) and u8.dtype == torch.uint8
+    with torch.no_grad():
+        ref = oracle(img.float().div(255).permute(0, 3, 1, 2)).clamp(0, 1).permute(0, 2, 3, 1)
+    p = psnr(f32.cpu(), ref, peak=1.0)
+    ref_u8 = np.stack([enhance_rgb_u8(oracle, im.numpy()) for im in img])
+    d = np.abs(u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
+    frac_mid = float(((ref > 0.02) & (ref < 0.98)).float().mean())
+    report(f"esrgan blocks={num_block} {n}x{H}x{W}: PSNR {p:.1f} dB, uint8 max|d| {int(d.max())}, mean|d| {d.mean():.3f}, "
+           f"unclamped fraction {frac_mid:.2f}")
+    assert frac_mid > 0.9, "synthetic output saturates: the comparison would be vacuous"
+    assert p >= 35.0
+    assert d.mean() < 1.5
+    # chunked execution (several frames per call, one frame per chunk) is bit-identical
+    engine.max_chunk_pixels = H * W
+    u8b, _ = engine(img.to(dev))
+    assert torch.equal(u8, u8b)
+
+
+def test_walk_upsample_layout(hip, dev, tmp_path):
+    """walk(upsample=True): same file layout as without, frames 4x larger (reference :513-516, :552)."""
+    from PIL import Image
+    from stable_diffusion_videos_amd.upsampling import RealESRGANModel
+    pipe = _tiny_pipeline(dev)
+    up = RealESRGANModel(None)
+    up.cfg.num_block = 1                                            # keep the test light: rebuild a 1-block generator
+    from stable_diffusion_videos_amd.weights import rrdbnet_shapes, synthetic_state_dict
+    up.state_dict_ = synthetic_state_dict(rrdbnet_shapes(up.cfg), seed=1)
+    pipe.upsampler = up
+    out = pipe.walk(prompts=["a", "b"], seeds=[1, 2], num_interpolation_steps=3, output_dir=str(tmp_path), name="u",
+                    num_inference_steps=2, height=64, width=64, batch_size=2, upsample=True, make_video=False)
+    assert out is None
+    frames = sorted((tmp_path / "u" / "u_000000").glob("frame*.png"))
+    assert len(frames) == 3
+    assert Image.open(frames[0]).size == (256, 256)
+    # single-image API of the reference class (float RGB in [0,1] -> PIL, BGR ndarray with convert_to_pil=False)
+    img = np.random.RandomState(0).rand(16, 24, 3).astype(np.float32)
+    pil = up(img)
+    assert pil.size == (96, 64)
+    bgr = up(img, convert_to_pil=False)
+    assert bgr.shape == (64, 96, 3) and np.array_equal(bgr[:, :, ::-1], np.asarray(pil))
+    assert up(img, outscale=2).size == (48, 32)

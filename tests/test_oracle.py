@@ -92,3 +92,31 @@ def test_tiny_oracle_end_to_end_runs():
     assert np.abs(frames.astype(int) - again.astype(int)).max() <= 1
     with pytest.raises(ValueError, match="Unexpected T shape"):
         pipeline.make_clip_frames(unet, vae, DDIMScheduler(), ea, eb, un, 1, 2, 4, 64, 64, T=np.linspace(0, 1, 3))
+
+
+def test_rrdbnet_oracle_schema_and_properties():
+    """Real-ESRGAN x4plus generator restatement: published parameter count and state-dict schema, output geometry,
+    and two exact properties of the architecture (zero network = zero image; the 0.2-scaled residual structure)."""
+    from oracle import esrgan
+    net = esrgan.RRDBNet().eval()
+    assert sum(p.numel() for p in net.parameters()) == 16_697_987          # RealESRGAN_x4plus.pth (params_ema)
+    keys = list(net.state_dict().keys())
+    assert keys[0] == "conv_first.weight" and "body.22.rdb3.conv5.bias" in keys and keys[-1] == "conv_last.bias"
+    assert net.state_dict()["body.0.rdb1.conv4.weight"].shape == (32, 160, 3, 3)
+    small = esrgan.RRDBNet(esrgan.RRDBNetConfig(num_block=1)).eval()
+    img = np.random.RandomState(0).randint(0, 256, (12, 20, 3), dtype=np.uint8)
+    out = esrgan.enhance_rgb_u8(small, img)
+    assert out.shape == (48, 80, 3) and out.dtype == np.uint8
+    with torch.no_grad():
+        for p in small.parameters():
+            p.zero_()
+        small.conv_last.bias.fill_(0.25)
+        assert np.all(esrgan.enhance_rgb_u8(small, img) == 64)             # round(0.25 * 255) = 64 (63.75)
+        # zero convs: every dense block returns 0 * 0.2 + x = x, so the RRDB returns x * 0.2 + x
+        blk = esrgan.RRDB(64, 32)
+        for p in blk.parameters():
+            p.zero_()
+        f = torch.randn(1, 64, 6, 6)
+        assert torch.allclose(blk(f), 1.2 * f)
+    with pytest.raises(ValueError):
+        esrgan.RRDBNet(esrgan.RRDBNetConfig(scale=2))
