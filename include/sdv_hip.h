@@ -54,6 +54,7 @@ int sdv_abi_version(void);
  *           1: GEGLU: W rows pre-interleaved per 32-row tile as [16 value | 16 gate]; out is [M][N/2]
  *           2: as 0, then SiLU
  *           3: as 0, then LeakyReLU(0.2)   (RRDBNet convs of the Real-ESRGAN upsampler, upsampling.py:25)
+ *           4: as 0, then quick_gelu x*sigmoid(1.702x) (CLIP ViT-L/14 text MLP);  5: as 0, then exact-erf GELU (OpenCLIP-H)
  * bias      fp32; bias_mode 1 = per n, 2 = per m.  If step_ptr != NULL the bias row used is
  *           bias + (*step_ptr) * bias_step_stride (per-denoise-step time-embedding bias table).
  * zero_page unused since ABI v1 kernels zero-fill padding through the buffer-descriptor range check (may be NULL).
@@ -88,11 +89,12 @@ int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
  *   Vt [B][H*dh][ldv] V TRANSPOSED (row = channel, column = key), ldv >= roundup(Lk,64), the
  *                     columns >= Lk must be finite (zero-filled)
  *   O  [B][Lq][ldo]
- * dh in {40, 64, 80, 160}.
+ * dh in {40, 64, 80, 160}.  causal != 0 masks key > query (CLIPTextModel's causal mask, reached from
+ * text_encoder(ids)[0], stable_diffusion_pipeline.py:819; needs Lq == Lk).
  * ------------------------------------------------------------------------------------------ */
 int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O,
                        int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dh,
-                       int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
+                       int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, int32_t causal, void* stream);
 
 /* row softmax in place over bf16 rows (VAE mid-block attention, 1 head x 512 channels) */
 int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, int32_t ld, void* stream);
@@ -182,6 +184,11 @@ int sdv_linear_small(const float* x, const sdv_bf16* w, const float* b, const fl
 int sdv_nchw_to_nhwc_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream);
 int sdv_nhwc_to_nchw_f32(const float* in, float* out, int32_t n, int32_t C, int32_t HW, void* stream);
 int sdv_f32_to_bf16(const float* in, sdv_bf16* out, int64_t n, void* stream);
+
+/* CLIP text encoder input (text_encoder(ids)[0], stable_diffusion_pipeline.py:819): out[t] = tok[ids[t]] + pos[t % L],
+ * fp32 tables -> bf16 rows; ids outside [0, vocab) are an error caught on the host side of the binding. */
+int sdv_embed_tokens(const int64_t* ids, const float* tok /*[vocab][D]*/, const float* pos /*[L][D]*/, sdv_bf16* out,
+                     int64_t n_tokens, int32_t L, int32_t D, int32_t vocab, void* stream);
 
 /* Real-ESRGAN x4 upsampler (upsampling.py:25-28, :46: RRDBNet inside RealESRGANer.enhance) - the glue around
  * sdv_gemm_bf16 / sdv_im2col3x3_c4 / sdv_conv3x3_cout_small:

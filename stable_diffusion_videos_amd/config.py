@@ -103,7 +103,7 @@ def tiny_vae() -> VAEConfig:
 
 def tiny_text() -> TextConfig:
     return TextConfig(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
-                      num_attention_heads=2, bos_token_id=998, eos_token_id=999)
+                      num_attention_heads=1, bos_token_id=998, eos_token_id=999)     # head dim 64, as in both SD text encoders
 
 
 def _from_json(cls, path: Path):

@@ -45,7 +45,7 @@ template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
-                                                        float scale_log2e) {
+                                                        float scale_log2e, int causal) {
     // QT = 32-query tiles per wave: the K / V^T fragments read from LDS are reused for QT MFMAs each.
     using Cfg = AttnCfg<DH>;
     constexpr int DKS = Cfg::DKS, DVT = Cfg::DVT, KROW = Cfg::KROW, VROW = Cfg::VROW;
@@ -223,13 +223,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         bf16x8_t pf[QT][4];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            if (kv0 + 64 > Lk) {
+            if (kv0 + 64 > Lk || causal) {
+                // causal (CLIP text encoder): key <= query.  Key 0 is visible to every query, so the first tile always
+                // sets a finite running max; later tiles may be fully masked for a lane (all P = 0).
+                const int klim = causal ? min(Lk, q0 + qt * 32 + l31 + 1) : Lk;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        s[qt][j][r] = key < Lk ? s[qt][j][r] : -INFINITY;
+                        s[qt][j][r] = key < klim ? s[qt][j][r] : -INFINITY;
                     }
             }
             float mx = s[qt][0][0];
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 
 template <int DH, int QT>
 int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
-                       int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+                       int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
     using Cfg = AttnCfg<DH>;
     dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
     // experiment knob, default OFF: one barrier per tile measured -4 % at dh = 40 (8 more VGPRs -> 3 waves / SIMD) and
@@ -370,7 +373,8 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
     const bool lean = lean_env && (DH % 32 != 0);   // dh = 64 / 160 have no padding rows or columns to exploit
     const float sl = scale * 1.4426950408889634f;
 #define SDV_ATTN_LAUNCH(P, L, D) \
-    hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl)
+    hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, \
+                       causal)
     if (!prio) SDV_ATTN_LAUNCH(false, false, false);      // reference variant kept for A/B runs (SDV_ATTN_PRIO=0)
     else if (lean && dbuf) SDV_ATTN_LAUNCH(true, true, true);
     else if (lean) SDV_ATTN_LAUNCH(true, true, false);
@@ -383,15 +387,15 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
 
 template <int DH>
 int launch_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
-                     int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+                     int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
     // 64 queries per wave halve the LDS fragment traffic and the barriers per MFMA; only worth it (and only
     // compiled) for the narrow heads and long sequences, where it fits the register file at 2 waves / SIMD.
     static const int qt_env = getenv("SDV_ATTN_QT") ? atoi(getenv("SDV_ATTN_QT")) : 0;   // experiment knob
     if constexpr (DH <= 64) {
         const bool two = qt_env ? qt_env == 2 : false;
-        if (two && Lq >= 1024) return launch_attention_q<DH, 2>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+        if (two && Lq >= 1024) return launch_attention_q<DH, 2>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
     }
-    return launch_attention_q<DH, 1>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+    return launch_attention_q<DH, 1>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
 }
 
 // ---- in-place row softmax over bf16 (VAE mid-block attention scores) -------------------------
@@ -437,17 +441,17 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(uint16_t* __restrict_
 
 extern "C" int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O, int32_t B,
                                   int32_t H, int32_t Lq, int32_t Lk, int32_t dh, int32_t ldq, int32_t ldk, int32_t ldv,
-                                  int32_t ldo, float scale, void* stream) {
+                                  int32_t ldo, float scale, int32_t causal, void* stream) {
     SDV_REQUIRE(Q && K && Vt && O, "sdv_attention_bf16: null pointer");
     SDV_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sdv_attention_bf16: bad shape");
     SDV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sdv_attention_bf16: unaligned leading dims");
     SDV_REQUIRE(ldv >= ((Lk + 63) / 64) * 64, "sdv_attention_bf16: ldv=%d must cover roundup(Lk=%d, 64)", ldv, Lk);
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
-        case 40: return launch_attention<40>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
-        case 64: return launch_attention<64>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
-        case 80: return launch_attention<80>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
-        case 160: return launch_attention<160>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, s);
+        case 40: return launch_attention<40>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        case 64: return launch_attention<64>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        case 80: return launch_attention<80>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        case 160: return launch_attention<160>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
         default: SDV_REQUIRE(false, "sdv_attention_bf16: unsupported head dim %d (40/64/80/160)", dh);
     }
     return SDV_OK;

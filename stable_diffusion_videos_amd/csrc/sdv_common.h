@@ -31,6 +31,7 @@ SDV_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
 SDV_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+SDV_DEVICE float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // CLIP 'quick_gelu'
 SDV_DEVICE float lrelu02_f(float x) { return x > 0.f ? x : 0.2f * x; }   // nn.LeakyReLU(negative_slope=0.2), RRDBNet
 // exact-erf GELU (F.gelu default, what diffusers' GEGLU uses) with a branch-free erf: Abramowitz-Stegun 7.1.26,
 // |abs error| < 1.5e-7 - three orders of magnitude below the bf16 output rounding - one v_rcp + one v_exp

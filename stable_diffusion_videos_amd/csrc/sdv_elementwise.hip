@@ -17,7 +17,7 @@ void sdv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sdv_last_error(void) { return g_err; }
-extern "C" int sdv_abi_version(void) { return 2; }
+extern "C" int sdv_abi_version(void) { return 3; }
 
 namespace {
 
@@ -213,6 +213,26 @@ __global__ __launch_bounds__(kThreads) void f32_to_bf16_kernel(const float* __re
                                                                long long n) {
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
         out[i] = f32_to_bf16(in[i]);
+}
+
+// CLIP text embeddings: out[t][:] = tok[ids[t]][:] + pos[t % L][:]  (fp32 tables, bf16 out); D % 4 == 0
+__global__ __launch_bounds__(kThreads) void embed_tokens_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                                                                const float* __restrict__ pos, uint16_t* __restrict__ out,
+                                                                long long n_tokens, int L, int D, int vocab) {
+    const int q = D >> 2;
+    const long long n = n_tokens * q;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const long long t = i / q;
+        const int c = (int)(i - t * q) * 4;
+        long long id = ids[t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // the binding rejects out-of-range ids; never read out of bounds
+        const float4 a = *(const float4*)(tok + id * D + c);
+        const float4 b = *(const float4*)(pos + (t % L) * D + c);
+        uint2 o;
+        o.x = pack_bf16x2(a.x + b.x, a.y + b.y);
+        o.y = pack_bf16x2(a.z + b.z, a.w + b.w);
+        *(uint2*)(out + t * D + c) = o;
+    }
 }
 
 // uint8 RGB pixels -> 4-channel bf16 rows {r, g, b, 0} * scale  (RealESRGANer.pre_process: img / 255)
@@ -513,6 +533,16 @@ extern "C" int sdv_f32_to_bf16(const float* in, sdv_bf16* out, int64_t n, void* 
     SDV_REQUIRE(in && out && n > 0, "sdv_f32_to_bf16: bad args");
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, in, out, (long long)n);
     SDV_CHECK_LAUNCH("sdv_f32_to_bf16");
+    return SDV_OK;
+}
+
+extern "C" int sdv_embed_tokens(const int64_t* ids, const float* tok, const float* pos, sdv_bf16* out, int64_t n_tokens,
+                                int32_t L, int32_t D, int32_t vocab, void* stream) {
+    SDV_REQUIRE(ids && tok && pos && out && n_tokens > 0 && L > 0 && vocab > 0, "sdv_embed_tokens: bad args");
+    SDV_REQUIRE(D > 0 && D % 4 == 0, "sdv_embed_tokens: D=%d must be a multiple of 4", D);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid_for(n_tokens * (D / 4))), dim3(kThreads), 0, (hipStream_t)stream, ids, tok,
+                       pos, out, (long long)n_tokens, L, D, vocab);
+    SDV_CHECK_LAUNCH("sdv_embed_tokens");
     return SDV_OK;
 }
 

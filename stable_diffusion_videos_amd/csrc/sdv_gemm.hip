@@ -379,6 +379,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                         } else if (p.epi == 3) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) f[e] = lrelu02_f(f[e]);
+                        } else if (p.epi == 4) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
+                        } else if (p.epi == 5) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
                         }
                         *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
                     }
@@ -466,6 +472,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                     } else if (p.epi == 3) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = lrelu02_f(v[e]);
+                    } else if (p.epi == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+                    } else if (p.epi == 5) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
                     }
                     uint2 o;
                     o.x = pack_bf16x2(v[0], v[1]);
@@ -479,6 +491,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                         if (R) t += bf16_to_f32(R[(long long)m * p.ldr + nb + e]);
                         if (p.epi == 2) t = silu_f(t);
                         if (p.epi == 3) t = lrelu02_f(t);
+                        if (p.epi == 4) t = quick_gelu_f(t);
+                        if (p.epi == 5) t = gelu_erf_f(t);
                         C[(long long)m * p.ldc + nb + e] = f32_to_bf16(t);
                     }
                 }
@@ -521,7 +535,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SDV_REQUIRE(a.K % 64 == 0, "sdv_gemm_bf16: K=%d must be a multiple of 64", a.K);
     SDV_REQUIRE(a.mode >= 0 && a.mode <= 3, "sdv_gemm_bf16: bad mode %d", a.mode);
-    SDV_REQUIRE(a.epi >= 0 && a.epi <= 3, "sdv_gemm_bf16: bad epi %d", a.epi);
+    SDV_REQUIRE(a.epi >= 0 && a.epi <= 5, "sdv_gemm_bf16: bad epi %d", a.epi);
     if (!a.X2) {
         a.C1 = a.K;
         a.ldx2 = a.ldx;

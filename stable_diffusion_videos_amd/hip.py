@@ -39,7 +39,7 @@ _SIGNATURES = {
     "sdv_last_error": (C.c_char_p, []),
     "sdv_abi_version": (C.c_int, []),
     "sdv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
-    "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_void_p]),
+    "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
@@ -61,6 +61,7 @@ _SIGNATURES = {
     "sdv_nchw_to_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sdv_embed_tokens": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_rgb_u8_to_bf16_c4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "sdv_axpby_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
                                  C.c_float, C.c_float, C.c_void_p]),
@@ -224,11 +225,13 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
 # attention / norms
 # ------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Lq: int,
-              Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0):
+              Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0,
+              causal: bool = False):
     lib = load()
     qp, kp, vp, op = _ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off, _ptr(vt, BF16, "Vt"), _ptr(out, BF16, "O")
     _launch("attention", dict(B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, flops=4.0 * B * H * Lq * Lk * dh),
-            lambda: _check(lib.sdv_attention_bf16(qp, kp, vp, op, B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, scale, _stream()),
+            lambda: _check(lib.sdv_attention_bf16(qp, kp, vp, op, B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, scale, int(causal),
+                                                  _stream()),
                            "sdv_attention_bf16"))
 
 
@@ -305,6 +308,22 @@ def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False, out=None):
     _launch("im2col_c4", dict(bytes=2.0 * nimg * H * W * (4 + 64)),
             lambda: _check(lib.sdv_im2col3x3_c4(xp, cp, nimg, H, W, int(circular), _stream()), "sdv_im2col3x3_c4"))
     return linear(cols, w_pad, bias, out=out)
+
+
+def embed_tokens(ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """CLIP input embeddings: ids int64 [B, L] -> bf16 [B*L, D] = tok[ids] + pos[position]."""
+    lib = load()
+    if ids.dtype != torch.int64 or ids.ndim != 2:
+        raise SdvHipError("embed_tokens: ids must be int64 [B, L]")
+    B, L = ids.shape
+    V, D = tok.shape
+    if L > pos.shape[0] or pos.shape[1] != D:
+        raise SdvHipError(f"embed_tokens: {L} positions / width {D} do not fit the position table {tuple(pos.shape)}")
+    ids = ids.contiguous()
+    out = torch.empty((B * L, D), dtype=BF16, device=ids.device)
+    _check(lib.sdv_embed_tokens(_ptr(ids, torch.int64, "ids"), _ptr(tok, F32, "tok"), _ptr(pos, F32, "pos"), _ptr(out, BF16),
+                                B * L, L, D, V, _stream()), "sdv_embed_tokens")
+    return out
 
 
 def rgb_u8_to_bf16_c4(img_u8: torch.Tensor, scale: float = 1.0 / 255.0) -> torch.Tensor:

@@ -13,7 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .config import RRDBNetConfig, UNetConfig, VAEConfig
+from .config import RRDBNetConfig, TextConfig, UNetConfig, VAEConfig
 
 StateDict = Dict[str, torch.Tensor]
 
@@ -134,6 +134,42 @@ def vae_decoder_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
     _norm(sd, "decoder.conv_norm_out", ch[-1])
     _conv(sd, "decoder.conv_out", ch[-1], cfg.out_channels, 3)
     return sd
+
+
+def clip_text_shapes(cfg: TextConfig) -> "OrderedDict[str, tuple]":
+    """``transformers.CLIPTextModel`` state-dict schema (5.x key names; older checkpoints prefix ``text_model.``)."""
+    sd: "OrderedDict[str, tuple]" = OrderedDict()
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    sd["embeddings.token_embedding.weight"] = (cfg.vocab_size, D)
+    sd["embeddings.position_embedding.weight"] = (cfg.max_position_embeddings, D)
+    for i in range(cfg.num_hidden_layers):
+        p = f"encoder.layers.{i}"
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            _lin(sd, f"{p}.self_attn.{n}", D, D)
+        _norm(sd, f"{p}.layer_norm1", D)
+        _lin(sd, f"{p}.mlp.fc1", D, I)
+        _lin(sd, f"{p}.mlp.fc2", I, D)
+        _norm(sd, f"{p}.layer_norm2", D)
+    _norm(sd, "final_layer_norm", D)
+    return sd
+
+
+def load_clip_text(model_dir: Path, shapes) -> StateDict:
+    d = Path(model_dir) / "text_encoder"
+    path = next((p for p in (d / "model.safetensors", d / "model.fp16.safetensors", d / "pytorch_model.bin") if p.exists()), None)
+    if path is None:
+        raise FileNotFoundError(f"no text encoder weights under {d}")
+    raw = {(k[len("text_model."):] if k.startswith("text_model.") else k): v for k, v in _load_file(path).items()}
+    missing = [k for k in shapes if k not in raw]
+    if missing:
+        raise KeyError(f"{path}: missing keys, e.g. {missing[:4]}")
+    out: StateDict = OrderedDict()
+    for k, shape in shapes.items():
+        t = raw[k].float()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{k}: shape {tuple(t.shape)} != expected {shape}")
+        out[k] = t
+    return out
 
 
 def rrdbnet_shapes(cfg: RRDBNetConfig) -> "OrderedDict[str, tuple]":

@@ -308,6 +308,47 @@ def test_attention_fused_qk_buffer_and_online_rescale(hip, dev):
     assert float((out.float().view(B, L, Cc)[0, 17] - ref[0, 17]).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("dh,L", [(64, 77), (64, 200), (40, 130), (80, 77), (160, 64)])
+def test_attention_causal(hip, dev, dh, L):
+    """CLIP text encoder form: causal mask, Lq = Lk = 77 (ragged last KV tile), fused [Q | K] buffer."""
+    B, heads = 3, 2
+    Cc = heads * dh
+    q, k, v = rnd((B, L, Cc), dev, 47), rnd((B, L, Cc), dev, 48), rnd((B, L, Cc), dev, 49)
+    scale = dh ** -0.5
+    qh, kh, vh = (t.view(B, L, heads, dh).transpose(1, 2) for t in (q, k, v))
+    mask = torch.full((L, L), float("-inf"), device=dev).triu(1)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale + mask, -1) @ vh).transpose(1, 2).reshape(B, L, Cc)
+    ldv = (L + 63) // 64 * 64
+    vt = torch.zeros((B, Cc, ldv), dtype=BF16, device=dev)
+    vt[:, :, :L] = v.transpose(1, 2).to(BF16)
+    qk = torch.cat([q, k], -1).reshape(-1, 2 * Cc).to(BF16).contiguous()
+    out = torch.empty((B * L, Cc), dtype=BF16, device=dev)
+    hip.attention(qk, qk, vt, out, B=B, H=heads, Lq=L, Lk=L, dh=dh, ldq=2 * Cc, ldk=2 * Cc, ldv=ldv, ldo=Cc, scale=scale,
+                  k_off=Cc, causal=True)
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().view(B, L, Cc), ref) < 6e-3
+    # token 0 sees only itself: its output is exactly (bf16 of) v[0]
+    assert float((out.float().view(B, L, Cc)[:, 0] - v[:, 0]).abs().max()) < 2e-2
+
+
+def test_clip_glue_kernels(hip, dev):
+    """embed_tokens and the quick_gelu / exact-GELU GEMM epilogues (CLIP text MLP)."""
+    g = torch.Generator().manual_seed(80)
+    V, L, D = 50, 77, 64
+    tok, pos = torch.randn((V, D), generator=g).to(dev), torch.randn((L, D), generator=g).to(dev)
+    ids = torch.randint(0, V, (3, L), generator=g).to(dev)
+    out = hip.embed_tokens(ids, tok, pos)
+    assert torch.equal(out.float().cpu(), bf16_round((tok[ids] + pos[None]).reshape(-1, D).cpu()))
+    M, N, K = 231, 192, 128
+    x, w, b = rnd((M, K), dev, 81), rnd((N, K), dev, 82, K ** -0.5), rnd((N,), dev, 83)
+    y = x @ w.T + b
+    for tile in (0, 1, 3):
+        q = hip.linear(x.to(BF16), w.to(BF16), b, epi=4, tile=tile)
+        assert rel_l2(q.float(), y * torch.sigmoid(1.702 * y)) < MFMA_TOL
+        e = hip.linear(x.to(BF16), w.to(BF16), b, epi=5, tile=tile)
+        assert rel_l2(e.float(), F.gelu(y)) < MFMA_TOL
+
+
 def test_softmax_rows(hip, dev):
     s = rnd((64, 512), dev, 46, 3.0)
     sb = s.to(BF16).contiguous()

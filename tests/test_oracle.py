@@ -120,3 +120,55 @@ def test_rrdbnet_oracle_schema_and_properties():
         assert torch.allclose(blk(f), 1.2 * f)
     with pytest.raises(ValueError):
         esrgan.RRDBNet(esrgan.RRDBNetConfig(scale=2))
+
+
+def _clip_golden(act):
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "golden" / f"clip_{act}.npz")
+    sd = {k[4:]: (torch.from_numpy(z[k].astype(np.int32)) << 16).view(torch.float32) for k in z.files if k.startswith("sd::")}
+    return z, sd
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_clip_oracle_pinned_against_transformers(act):
+    """oracle/clip.py vs last_hidden_state of the real transformers.CLIPTextModel: the committed vectors, and the live
+    model when transformers can be imported (it is part of this image).  fp32 on both sides: 5e-4 absolute on values
+    of magnitude ~15 (attention is evaluated in a different association order)."""
+    from oracle.clip import clip_text_forward
+    z, sd = _clip_golden(act)
+    ids = torch.from_numpy(z["ids"])
+    out = clip_text_forward(sd, ids, int(z["num_heads"]), act)
+    assert float((out - torch.from_numpy(z["last_hidden_state"])).abs().max()) < 5e-4
+    # prefixed (transformers < 5) state dicts are accepted too
+    out2 = clip_text_forward({"text_model." + k: v for k, v in sd.items()}, ids, int(z["num_heads"]), act)
+    assert torch.equal(out, out2)
+    # causality: changing a later token never changes an earlier position
+    ids2 = ids.clone()
+    ids2[:, 40:] = 5
+    assert torch.equal(clip_text_forward(sd, ids2, int(z["num_heads"]), act)[:, :40], out[:, :40])
+    try:
+        from transformers import CLIPTextConfig, CLIPTextModel
+    except Exception:
+        return
+    D = sd["final_layer_norm.weight"].numel()
+    nl = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
+    cfg = CLIPTextConfig(vocab_size=sd["embeddings.token_embedding.weight"].shape[0], hidden_size=D,
+                         intermediate_size=sd["encoder.layers.0.mlp.fc1.weight"].shape[0], num_hidden_layers=nl,
+                         num_attention_heads=int(z["num_heads"]), max_position_embeddings=77, hidden_act=act,
+                         bos_token_id=209, eos_token_id=210, pad_token_id=210, projection_dim=64)
+    model = CLIPTextModel(cfg).float().eval()
+    missing = model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if "position_ids" not in k]
+    with torch.no_grad():
+        live = model(ids)[0]
+    assert float((out - live).abs().max()) < 5e-4
+
+
+def test_clip_shape_table_matches_transformers_schema():
+    from stable_diffusion_videos_amd import config as cfgs
+    from stable_diffusion_videos_amd.weights import clip_text_shapes, count_params
+    _, sd = _clip_golden("quick_gelu")
+    cfg = cfgs.TextConfig(vocab_size=211, hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2)
+    shapes = clip_text_shapes(cfg)
+    assert set(shapes) == set(sd) and all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert count_params(clip_text_shapes(cfgs.sd14_text())) == 123_060_480      # CLIP ViT-L/14 text tower
