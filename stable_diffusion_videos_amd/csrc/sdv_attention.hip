@@ -41,7 +41,7 @@ struct AttnCfg {
     static constexpr int VPT = (VCH + 255) / 256;
 };
 
-template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF>
+template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF, bool PP = false>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -199,6 +199,96 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             if (t + 1 < ntiles) load_tile((t + 1) * 64);
         }
 
+        if constexpr (PP) {
+            // ---- software-pipelined body (dh = 40, two 32-query tiles per wave, full key tiles, no mask) -------------
+            // The two query tiles are skewed by half a step so that every VALU phase of one has MFMAs of the other to
+            // hide behind (the softmax here is ~95 VALU per 14 MFMAs - far above what one wave can hide per MFMA):
+            //   S0 = K.Q0        | X: S1 (first key half) || max(S0)    | Y: S1 (second half) || P0 = exp2(S0)
+            //   Z: O0 += V.P0 (d-tile 0) || max(S1)  | W: O0 += V.P0 (d-tile 1) || P1 = exp2(S1) | V: O1 += V.P1
+            static_assert(QT == 2 && PADM && ONES && !DBUF, "PP: dh = 40 LEAN kernel with two query tiles");
+            bf16x8_t kfr[2][DKS];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < DKS; ++ks)
+                    kfr[j][ks] = *(const bf16x8_t*)(ldsK + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
+            auto qk = [&](int qt, int j) {
+                f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[j][0], qf[qt][0], kZero16, 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < DKS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[j][ks], qf[qt][ks], acc, 0, 0, 0);
+                return acc;
+            };
+            auto tile_max = [&](const f32x16_t& a, const f32x16_t& b) {
+                float mx = a[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, a[r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, b[r]);
+                return fmaxf(mx, __shfl_xor(mx, 32));
+            };
+            auto rescale = [&](int qt, float mx, f32x16_t& a, f32x16_t& b) {   // rare: the running max moved by > 2^kDefer
+                const float want = m_run[qt] + (t == 0 ? mx : fmaxf(mx, 0.f));
+                const uint32_t mbits = pack_bf16x2(want, 0.f) << 16;
+                const float m_new = __builtin_bit_cast(float, mbits);
+                const float delta = m_new - m_run[qt];
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run[qt] = m_new;
+                u32x4_t qw = __builtin_bit_cast(u32x4_t, qf[qt][PADM_KS]);
+                qw[0] = lhi ? ((mbits ^ 0x80000000u) >> 16) : qw[0];
+                qf[qt][PADM_KS] = __builtin_bit_cast(bf16x8_t, qw);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    a[r] -= delta;
+                    b[r] -= delta;
+                }
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
+            };
+            auto exp_half = [&](const f32x16_t& a, bf16x8_t* pq) {             // 16 scores -> two B fragments
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    u32x4_t pr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        pr[e] = pack_bf16x2(__builtin_amdgcn_exp2f(a[8 * u + 2 * e]), __builtin_amdgcn_exp2f(a[8 * u + 2 * e + 1]));
+                    pq[u] = __builtin_bit_cast(bf16x8_t, pr);
+                }
+            };
+            auto vfrag = [&](int dt, int ju) {
+                return *(const bf16x8_t*)(ldsV + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
+            };
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+            f32x16_t s0a = qk(0, 0), s0b = qk(0, 1);
+            // X: first key half of S1 beside the max of S0
+            f32x16_t s1a = qk(1, 0);
+            float mx = tile_max(s0a, s0b);
+            if (t == 0 || !__all(mx <= kDefer)) rescale(0, mx, s0a, s0b);
+            // Y: second key half of S1 beside P0 = exp2(S0)
+            f32x16_t s1b = qk(1, 1);
+            bf16x8_t p0[4], p1[4];
+            exp_half(s0a, p0);
+            exp_half(s0b, p0 + 2);
+            // Z: O0 d-tile 0 beside the max of S1
+#pragma unroll
+            for (int ju = 0; ju < 4; ++ju) o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(0, ju), p0[ju], o[0][0], 0, 0, 0);
+            mx = tile_max(s1a, s1b);
+            if (t == 0 || !__all(mx <= kDefer)) rescale(1, mx, s1a, s1b);
+            // W: O0 d-tile 1 beside P1 = exp2(S1)
+#pragma unroll
+            for (int ju = 0; ju < 4; ++ju) o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(1, ju), p0[ju], o[0][1], 0, 0, 0);
+            exp_half(s1a, p1);
+            exp_half(s1b, p1 + 2);
+            // V: O1
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                for (int ju = 0; ju < 4; ++ju)
+                    o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(dt, ju), p1[ju], o[1][dt], 0, 0, 0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
         // ---- S^T = K . Q^T for two 32-key subtiles (each K fragment feeds QT MFMAs) ----
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);   // matrix-pipe clusters win issue arbitration (guide T5)
         f32x16_t s[QT][2];
@@ -375,6 +465,16 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
 #define SDV_ATTN_LAUNCH(P, L, D) \
     hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, \
                        causal)
+    if constexpr (DH == 40 && QT == 2) {
+        // software-pipelined two-query-tile kernel: full key tiles only, no mask (the 64^2 self-attention)
+        static const bool pp_env = !(getenv("SDV_ATTN_PP") && atoi(getenv("SDV_ATTN_PP")) == 0);
+        if (pp_env && prio && lean && !dbuf && !causal && Lk % 64 == 0) {
+            hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk,
+                               ldq, ldk, ldv, ldo, sl, causal);
+            SDV_CHECK_LAUNCH("sdv_attention_bf16");
+            return SDV_OK;
+        }
+    }
     if (!prio) SDV_ATTN_LAUNCH(false, false, false);      // reference variant kept for A/B runs (SDV_ATTN_PRIO=0)
     else if (lean && dbuf) SDV_ATTN_LAUNCH(true, true, true);
     else if (lean) SDV_ATTN_LAUNCH(true, true, false);
@@ -388,11 +488,13 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
 template <int DH>
 int launch_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
                      int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
-    // 64 queries per wave halve the LDS fragment traffic and the barriers per MFMA; only worth it (and only
-    // compiled) for the narrow heads and long sequences, where it fits the register file at 2 waves / SIMD.
-    static const int qt_env = getenv("SDV_ATTN_QT") ? atoi(getenv("SDV_ATTN_QT")) : 0;   // experiment knob
+    // Two 32-query tiles per wave (halves the LDS fragment traffic and barriers per MFMA, 2 waves / SIMD).  Plain QT = 2
+    // measured -3 % .. +1 %; with the software-pipelined body (PP: dh = 40, full key tiles, no mask - the 64^2
+    // self-attention) +5.5 %, so that combination is the default.  SDV_ATTN_QT=1 / 2 force either form.
+    static const int qt_env = getenv("SDV_ATTN_QT") ? atoi(getenv("SDV_ATTN_QT")) : 0;
     if constexpr (DH <= 64) {
-        const bool two = qt_env ? qt_env == 2 : false;
+        const bool pp_ok = DH == 40 && !causal && Lk % 64 == 0;
+        const bool two = qt_env ? qt_env == 2 : pp_ok;
         if (two && Lq >= 1024) return launch_attention_q<DH, 2>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
     }
     return launch_attention_q<DH, 1>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
