@@ -203,8 +203,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             // ---- software-pipelined body (dh = 40, two 32-query tiles per wave, full key tiles, no mask) -------------
             // The two query tiles are skewed by half a step so that every VALU phase of one has MFMAs of the other to
             // hide behind (the softmax here is ~95 VALU per 14 MFMAs - far above what one wave can hide per MFMA):
-            //   S0 = K.Q0        | X: S1 (first key half) || max(S0)    | Y: S1 (second half) || P0 = exp2(S0)
-            //   Z: O0 += V.P0 (d-tile 0) || max(S1)  | W: O0 += V.P0 (d-tile 1) || P1 = exp2(S1) | V: O1 += V.P1
+            //   S0 = K.Q0 | S1 = K.Q1 || max(S0) | { P0 quarter = exp2(S0 quarter); O0 += V.P0 quarter } x 4 | max(S1) |
+            //   { P1 quarter = exp2(S1 quarter); O1 += V.P1 quarter } x 4
             static_assert(QT == 2 && PADM && ONES && !DBUF, "PP: dh = 40 LEAN kernel with two query tiles");
             bf16x8_t kfr[2][DKS];
 #pragma unroll
@@ -246,46 +246,37 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
                     for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
             };
-            auto exp_half = [&](const f32x16_t& a, bf16x8_t* pq) {             // 16 scores -> two B fragments
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    u32x4_t pr;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        pr[e] = pack_bf16x2(__builtin_amdgcn_exp2f(a[8 * u + 2 * e]), __builtin_amdgcn_exp2f(a[8 * u + 2 * e + 1]));
-                    pq[u] = __builtin_bit_cast(bf16x8_t, pr);
-                }
-            };
             auto vfrag = [&](int dt, int ju) {
                 return *(const bf16x8_t*)(ldsV + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
             };
+            auto exp_quarter = [&](const f32x16_t& a, int u) {                  // 8 scores -> one B fragment
+                u32x4_t pr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    pr[e] = pack_bf16x2(__builtin_amdgcn_exp2f(a[8 * u + 2 * e]), __builtin_amdgcn_exp2f(a[8 * u + 2 * e + 1]));
+                return __builtin_bit_cast(bf16x8_t, pr);
+            };
+            // P quarter ju = (key half j, register half u) feeds both d-tiles straight away: the v_exp_f32 stream (the
+            // transcendental unit costs ~11 cycles per wave instruction, tools/ubench/valu_rate.hip) runs beside the
+            // PV MFMAs of the same query tile instead of in front of them
+            auto softmax_pv = [&](int qt, const f32x16_t& a, const f32x16_t& b) {
+#pragma unroll
+                for (int ju = 0; ju < 4; ++ju) {
+                    const bf16x8_t pq = exp_quarter(ju < 2 ? a : b, ju & 1);
+#pragma unroll
+                    for (int dt = 0; dt < DVT; ++dt)
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(dt, ju), pq, o[qt][dt], 0, 0, 0);
+                }
+            };
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
             f32x16_t s0a = qk(0, 0), s0b = qk(0, 1);
-            // X: first key half of S1 beside the max of S0
-            f32x16_t s1a = qk(1, 0);
+            f32x16_t s1a = qk(1, 0), s1b = qk(1, 1);                           // in flight beside max(S0)
             float mx = tile_max(s0a, s0b);
             if (t == 0 || !__all(mx <= kDefer)) rescale(0, mx, s0a, s0b);
-            // Y: second key half of S1 beside P0 = exp2(S0)
-            f32x16_t s1b = qk(1, 1);
-            bf16x8_t p0[4], p1[4];
-            exp_half(s0a, p0);
-            exp_half(s0b, p0 + 2);
-            // Z: O0 d-tile 0 beside the max of S1
-#pragma unroll
-            for (int ju = 0; ju < 4; ++ju) o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(0, ju), p0[ju], o[0][0], 0, 0, 0);
+            softmax_pv(0, s0a, s0b);
             mx = tile_max(s1a, s1b);
             if (t == 0 || !__all(mx <= kDefer)) rescale(1, mx, s1a, s1b);
-            // W: O0 d-tile 1 beside P1 = exp2(S1)
-#pragma unroll
-            for (int ju = 0; ju < 4; ++ju) o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(1, ju), p0[ju], o[0][1], 0, 0, 0);
-            exp_half(s1a, p1);
-            exp_half(s1b, p1 + 2);
-            // V: O1
-#pragma unroll
-            for (int dt = 0; dt < DVT; ++dt)
-#pragma unroll
-                for (int ju = 0; ju < 4; ++ju)
-                    o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(dt, ju), p1[ju], o[1][dt], 0, 0, 0);
+            softmax_pv(1, s1a, s1b);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             continue;
         }
