@@ -19,6 +19,10 @@
 
 #include "sdv_common.h"
 
+#ifndef SDV_WHATIF
+#define SDV_WHATIF 0
+#endif
+
 namespace {
 
 constexpr f32x16_t kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -37,17 +41,22 @@ struct AttnCfg {
     static constexpr int CPR = DH / 8;                // 16-B chunks per K row
     static constexpr int KCH = 64 * CPR;              // chunks per K tile
     static constexpr int VCH = DH * 8;                // chunks per V^T tile
-    static constexpr int KPT = (KCH + 255) / 256;     // chunks per thread
+    static constexpr int KPT = (KCH + 255) / 256;     // chunks per thread (4-wave workgroup)
     static constexpr int VPT = (VCH + 255) / 256;
 };
 
-template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF, bool PP = false>
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
+template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF, bool PP = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
-                                                        float scale_log2e, int causal) {
+                                                        float scale_log2e, int causal, int BH) {
     // QT = 32-query tiles per wave: the K / V^T fragments read from LDS are reused for QT MFMAs each.
+    // NW = waves per workgroup: one staged K / V^T tile serves NW * QT * 32 queries (staging a tile costs ~17 % of the
+    //      4-wave kernel's time in VMEM / LDS-write issue, tools/ubench/build_whatif.py variants 4-6).
     using Cfg = AttnCfg<DH>;
+    constexpr int NT = NW * 64;
+    constexpr int KPT = (Cfg::KCH + NT - 1) / NT, VPT = (Cfg::VCH + NT - 1) / NT;
+    static_assert(Cfg::KCH % 64 == 0 && Cfg::VCH % 64 == 0, "staging predicates must be wave-uniform");
     constexpr int DKS = Cfg::DKS, DVT = Cfg::DVT, KROW = Cfg::KROW, VROW = Cfg::VROW;
     // LEAN softmax - the dh = 40 / 80 kernels are VALU-issue-bound, not MFMA-bound (~150 VALU per 14 MFMAs at dh = 40):
     //  * Q is pre-multiplied by scale*log2(e) when its fragments are loaded, so scores come out of the MFMA in log2 units;
@@ -70,15 +79,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar branches on it)
     const int l31 = lane & 31;
     const int lhi = lane >> 5;
-    const int h = blockIdx.y;
-    const int b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * (32 * QT);
+    // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (8 private L2s).  All
+    // query blocks of one (batch, head) stream the SAME K / V^T (655 KB at 64^2), so they are mapped to ONE XCD, back to
+    // back: workgroup w -> XCD w & 7, position i = w >> 3 inside it -> head group i / nqb, query block i % nqb.
+    const int nqb = (Lq + 32 * NW * QT - 1) / (32 * NW * QT);
+    const int wg_i = blockIdx.x >> 3;
+    const int bh = (wg_i / nqb) * 8 + (blockIdx.x & 7);
+    if (bh >= BH) return;                     // BH = batch * heads; the grid is padded to 8 head slots per group
+    const int h = bh % H;
+    const int b = bh / H;
+    const int q0 = ((wg_i % nqb) * NW + wave) * (32 * QT);
 
     // zero the LDS pads once: K columns [DH, DKP) and V^T rows [DH, DVP) are never rewritten
-    for (int i = tid; i < NBUF * KV_BYTES / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < NBUF * KV_BYTES / 16; i += NT) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
     if constexpr (ONES) {
         __syncthreads();
         for (int bf = 0; bf < NBUF; ++bf) {
@@ -119,48 +135,63 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     }
 
     // ---- register staging of the next K / V^T tile --------------------------------------------
-    u32x4_t kreg[Cfg::KPT], vreg[Cfg::VPT];
+    u32x4_t kreg[KPT], vreg[VPT];
     const uint16_t* Kb = Kp + (long long)b * Lk * ldk + h * DH;
     const uint16_t* Vb = Vt + ((long long)b * H + h) * DH * ldv;
     // (chunk indices are clamped instead of predicated: surplus threads re-load / re-store the last
     //  chunk with identical data, which keeps the staging registers free of divergent control flow)
+    // Buffer loads: the per-lane byte offsets are tile-invariant (computed once, here) and the tile position travels in
+    // the SCALAR offset, so staging a tile costs no VALU address arithmetic (the what-if build without staging ran 19 %
+    // faster - most of that was 64-bit address math, clamps and waits, not bandwidth).  Keys beyond Lk fall outside
+    // num_records and read as zero.
+    const __amdgpu_buffer_rsrc_t rs_k =
+        __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(Lk - 1) * ldk + DH) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((long long)DH * ldv * 2), 0x00020000);
+    int kvo[KPT], vvo[VPT];
+    // chunk c of a tile belongs to thread c % NT; KCH and VCH are multiples of 64, so "c < KCH" is the same for all
+    // lanes of a wave: surplus WAVES skip their loads / stores altogether (no divergence, no redundant traffic)
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int c = tid + i * NT;
+        const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
+        kvo[i] = (row * ldk + cc * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = tid + i * NT;
+        const int row = c >> 3, cc = c & 7;
+        vvo[i] = (row * ldv + cc * 8) * 2;
+    }
     auto load_tile = [&](int kv0) {
+        const int ks_off = kv0 * ldk * 2, vs_off = kv0 * 2;
 #pragma unroll
-        for (int i = 0; i < Cfg::KPT; ++i) {
-            int c = tid + i * 256;
-            c = c < Cfg::KCH ? c : Cfg::KCH - 1;
-            const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
-            int key = kv0 + row;
-            key = key < Lk ? key : Lk - 1;
-            kreg[i] = *(const u32x4_t*)(Kb + (long long)key * ldk + cc * 8);
-        }
+        for (int i = 0; i < KPT; ++i)
+            if (wave * 64 + i * NT < Cfg::KCH)
+                kreg[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_k, kvo[i], ks_off, 0));
 #pragma unroll
-        for (int i = 0; i < Cfg::VPT; ++i) {
-            int c = tid + i * 256;
-            c = c < Cfg::VCH ? c : Cfg::VCH - 1;
-            const int row = c >> 3, cc = c & 7;
-            vreg[i] = *(const u32x4_t*)(Vb + (long long)row * ldv + kv0 + cc * 8);
-        }
+        for (int i = 0; i < VPT; ++i)
+            if (wave * 64 + i * NT < Cfg::VCH)
+                vreg[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vvo[i], vs_off, 0));
     };
     auto store_tile = [&](int boff) {
 #pragma unroll
-        for (int i = 0; i < Cfg::KPT; ++i) {
-            int c = tid + i * 256;
-            c = c < Cfg::KCH ? c : Cfg::KCH - 1;
+        for (int i = 0; i < KPT; ++i) {
+            const int c = tid + i * NT;
             const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
-            *(u32x4_t*)(ldsK + boff + row * KROW + cc * 16) = kreg[i];
+            if (wave * 64 + i * NT < Cfg::KCH) *(u32x4_t*)(ldsK + boff + row * KROW + cc * 16) = kreg[i];
         }
         // V^T row d holds 64 keys; within each 16-key block the 4-key groups are stored in the order
         // [0-3][8-11][4-7][12-15] so that one ds_read_b128 at (block*16 + lhi*8) keys yields exactly
         // the keys this lane's P registers hold (MFMA 32x32 C-layout: key = (r&3) + 8*(r>>2) + 4*lhi).
 #pragma unroll
-        for (int i = 0; i < Cfg::VPT; ++i) {
-            int c = tid + i * 256;
-            c = c < Cfg::VCH ? c : Cfg::VCH - 1;
+        for (int i = 0; i < VPT; ++i) {
+            const int c = tid + i * NT;
             const int row = c >> 3, cc = c & 7;  // cc: 8-key chunk; block = cc>>1, half = cc&1
-            char* dst = ldsV + boff + row * VROW + (cc >> 1) * 32 + (cc & 1) * 8;
-            *(u32x2_t*)(dst) = u32x2_t{vreg[i][0], vreg[i][1]};        // keys +0..3
-            *(u32x2_t*)(dst + 16) = u32x2_t{vreg[i][2], vreg[i][3]};   // keys +4..7
+            if (wave * 64 + i * NT < Cfg::VCH) {
+                char* dst = ldsV + boff + row * VROW + (cc >> 1) * 32 + (cc & 1) * 8;
+                *(u32x2_t*)(dst) = u32x2_t{vreg[i][0], vreg[i][1]};        // keys +0..3
+                *(u32x2_t*)(dst + 16) = u32x2_t{vreg[i][2], vreg[i][3]};   // keys +4..7
+            }
         }
     };
 
@@ -193,10 +224,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 if (t + 2 < ntiles) load_tile((t + 2) * 64);
             }
         } else {
+#if SDV_WHATIF == 2       // timing experiment: what do the two barriers cost?  (racy)
+            store_tile(0);
+            if (t + 1 < ntiles) load_tile((t + 1) * 64);
+#elif SDV_WHATIF == 4     // timing experiment: what does the K / V staging cost?  (one tile reused)
+            if (t == 0) {
+                __syncthreads();
+                store_tile(0);
+                __syncthreads();
+            }
+#elif SDV_WHATIF == 5     // timing experiment: global loads kept, LDS stores skipped after the first tile
+            __syncthreads();
+            if (t == 0) store_tile(0);
+            __syncthreads();
+            if (t + 1 < ntiles) load_tile((t + 1) * 64);
+            if (t + 1 == ntiles) asm volatile("" ::"v"(kreg[0]), "v"(vreg[0]));
+#elif SDV_WHATIF == 6     // timing experiment: LDS stores + barriers kept, global loads skipped after the first tile
+            __syncthreads();
+            store_tile(0);
+            __syncthreads();
+#else
             __syncthreads();  // previous tile fully consumed (and the pad zeroing is visible)
             store_tile(0);
             __syncthreads();
             if (t + 1 < ntiles) load_tile((t + 1) * 64);
+#endif
         }
 
         if constexpr (PP) {
@@ -220,6 +272,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             };
             auto tile_max = [&](const f32x16_t& a, const f32x16_t& b) {
                 float mx = a[0];
+#if SDV_WHATIF == 3   // timing experiment: what does the row max cost?  (wrong results)
+                return fmaxf(mx, b[3]);
+#endif
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, a[r]);
 #pragma unroll
@@ -253,7 +308,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 u32x4_t pr;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
+#if SDV_WHATIF == 1   // timing experiment (tools/ubench/build_whatif.py): what do the exps cost?  (wrong results)
+                    pr[e] = pack_bf16x2(a[8 * u + 2 * e] * 0.5f, a[8 * u + 2 * e + 1] * 0.5f);
+#else
                     pr[e] = pack_bf16x2(__builtin_amdgcn_exp2f(a[8 * u + 2 * e]), __builtin_amdgcn_exp2f(a[8 * u + 2 * e + 1]));
+#endif
                 return __builtin_bit_cast(bf16x8_t, pr);
             };
             // P quarter ju = (key half j, register half u) feeds both d-tiles straight away: the v_exp_f32 stream (the
@@ -443,7 +502,8 @@ template <int DH, int QT>
 int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
     using Cfg = AttnCfg<DH>;
-    dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
+    const int nqb = (Lq + 128 * QT - 1) / (128 * QT);
+    dim3 grid(nqb * (((B * H + 7) / 8) * 8));             // 1-D over (head group, query block, XCD slot)
     // experiment knob, default OFF: one barrier per tile measured -4 % at dh = 40 (8 more VGPRs -> 3 waves / SIMD) and
     // +-0 at dh = 80; the two barriers are not what limits this kernel.
     static const bool dbuf_env = getenv("SDV_ATTN_DBUF") && atoi(getenv("SDV_ATTN_DBUF")) != 0;
@@ -455,13 +515,22 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
     const float sl = scale * 1.4426950408889634f;
 #define SDV_ATTN_LAUNCH(P, L, D) \
     hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, \
-                       causal)
+                       causal, B * H)
     if constexpr (DH == 40 && QT == 2) {
         // software-pipelined two-query-tile kernel: full key tiles only, no mask (the 64^2 self-attention)
         static const bool pp_env = !(getenv("SDV_ATTN_PP") && atoi(getenv("SDV_ATTN_PP")) == 0);
         if (pp_env && prio && lean && !dbuf && !causal && Lk % 64 == 0) {
-            hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk,
-                               ldq, ldk, ldv, ldo, sl, causal);
+            // experiment knob, default OFF: 8 waves per workgroup (one staged K / V^T tile serves 512 queries instead of
+            // 256) measured +-0 against 4 waves - halving the staging traffic per query does not buy anything
+            static const bool w8 = getenv("SDV_ATTN_NW") && atoi(getenv("SDV_ATTN_NW")) == 8;
+            if (w8) {
+                const int nqb8 = (Lq + 511) / 512;
+                hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true, 8>), dim3(nqb8 * (((B * H + 7) / 8) * 8)),
+                                   dim3(512), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, causal, B * H);
+            } else {
+                hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq,
+                                   Lk, ldq, ldk, ldv, ldo, sl, causal, B * H);
+            }
             SDV_CHECK_LAUNCH("sdv_attention_bf16");
             return SDV_OK;
         }

@@ -7,12 +7,14 @@ There is NO fallback: if the library is missing or a tensor is not on the GPU th
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Optional
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsdv_hip.so"
+# SDV_HIP_LIB: developer knob - load an alternative build of the SAME C ABI (tools/ubench/build_whatif.py timing variants)
+_LIB_PATH = Path(os.environ["SDV_HIP_LIB"]) if os.environ.get("SDV_HIP_LIB") else Path(__file__).resolve().parent / "lib" / "libsdv_hip.so"
 _lib = None
 
 
