@@ -33,6 +33,10 @@ namespace {
 template <int WM, int WN, int TM, int TN, int BK, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) void igemm_kernel(const sdv_gemm_args p) {
     constexpr int NWV = WM * WN;            // waves per workgroup (4 or 8)
+    // The extra activations (epi 3 LeakyReLU, 4 quick_gelu, 5 GELU: RRDBNet / CLIP text encoder) are compiled into the
+    // 4-wave tiles only: the 8-wave 256x320 tile has no VGPRs to spare (adding them to its epilogue spilled 768 B of
+    // scratch and cost 5x on every UNet GEMM), and those networks' shapes use the small tiles anyway.
+    constexpr bool XACT = NWV == 4;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int ROWB = BK * 2;            // bytes per LDS row (128 or 64)
@@ -376,15 +380,18 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                         if (p.epi == 2) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
-                        } else if (p.epi == 3) {
+                        }
+                        if constexpr (XACT) {
+                            if (p.epi == 3) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] = lrelu02_f(f[e]);
-                        } else if (p.epi == 4) {
+                                for (int e = 0; e < 8; ++e) f[e] = lrelu02_f(f[e]);
+                            } else if (p.epi == 4) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
-                        } else if (p.epi == 5) {
+                                for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
+                            } else if (p.epi == 5) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
+                                for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
+                            }
                         }
                         *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
                     }
@@ -469,15 +476,18 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                     if (p.epi == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                    } else if (p.epi == 3) {
+                    }
+                    if constexpr (XACT) {
+                        if (p.epi == 3) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = lrelu02_f(v[e]);
-                    } else if (p.epi == 4) {
+                            for (int e = 0; e < 4; ++e) v[e] = lrelu02_f(v[e]);
+                        } else if (p.epi == 4) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
-                    } else if (p.epi == 5) {
+                            for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+                        } else if (p.epi == 5) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                        }
                     }
                     uint2 o;
                     o.x = pack_bf16x2(v[0], v[1]);
@@ -490,9 +500,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                         float t = v[e];
                         if (R) t += bf16_to_f32(R[(long long)m * p.ldr + nb + e]);
                         if (p.epi == 2) t = silu_f(t);
-                        if (p.epi == 3) t = lrelu02_f(t);
-                        if (p.epi == 4) t = quick_gelu_f(t);
-                        if (p.epi == 5) t = gelu_erf_f(t);
+                        if constexpr (XACT) {
+                            if (p.epi == 3) t = lrelu02_f(t);
+                            if (p.epi == 4) t = quick_gelu_f(t);
+                            if (p.epi == 5) t = gelu_erf_f(t);
+                        }
                         C[(long long)m * p.ldc + nb + e] = f32_to_bf16(t);
                     }
                 }
@@ -582,6 +594,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         //  128x64 tile wins or ties everywhere - tools/esrgan_tile_sweep.py, profiles/round1_esrgan.txt)
         double best = 1e300;
         for (const Cand& c : cands) {
+            if (a.epi >= 3 && c.id >= 6) continue;   // extended activations exist in the 4-wave tiles only
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
             const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {
@@ -590,6 +603,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
             }
         }
     }
+    SDV_REQUIRE(!(a.epi >= 3 && tile >= 6 && tile <= 9), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2, 64>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
