@@ -254,3 +254,25 @@ def test_realesrgan_surface_and_weights(tmp_path):
         RealESRGANModel(None, tile=256)
     with pytest.raises(FileNotFoundError):
         m.upsample_imagefolder(tmp_path / "missing", tmp_path / "out")
+
+
+def test_hot_kernels_do_not_spill():
+    """Guard against register-pressure regressions in the kernels the roofline depends on: compile sdv_gemm.hip /
+    sdv_attention.hip with the build's own flags plus -Rpass-analysis=kernel-resource-usage and check scratch use.
+    (Adding two activation branches to the igemm epilogue once pushed the 256x320 tile from 64 B to 768 B of scratch per
+    lane - every test still passed, the bench lost 4x.)"""
+    import re
+    import subprocess
+    from stable_diffusion_videos_amd import build as b
+    budget = {"sdv_gemm.hip": 128, "sdv_attention.hip": 0}       # bytes of scratch per lane allowed (epilogue-only slots)
+    for name, limit in budget.items():
+        src = b.CSRC / name
+        cmd = [b.hipcc(), *b.FLAGS, *b.FAST_FLAGS, *b.EXTRA_FLAGS.get(name, []), "-Rpass-analysis=kernel-resource-usage", "-c",
+               str(src), "-o", "/dev/null"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        names = re.findall(r"Function Name: (\S+)", r.stderr)
+        scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+        assert names and len(names) == len(scratch)
+        worst = max(zip(scratch, names))
+        assert worst[0] <= limit, f"{name}: kernel {worst[1]} uses {worst[0]} B of scratch per lane (limit {limit})"
