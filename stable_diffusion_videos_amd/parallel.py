@@ -100,6 +100,10 @@ def broadcast_state_dict(sd: Dict[str, torch.Tensor], shapes: Dict[str, tuple], 
             o += n
     dist.broadcast(buf_m, src=src)
     dist.broadcast(buf_v, src=src)
+    if use_gpu:
+        # hand the engines host tensors, exactly as in the single-GPU path (the per-layer re-layout then uploads bf16):
+        # one 1.7 GB D2H copy per rank at start-up buys ONE weight code path for 1 and N GPUs
+        buf_m, buf_v = buf_m.cpu(), buf_v.cpu()
     out: Dict[str, torch.Tensor] = {}
     o = 0
     for k in mats:
