@@ -4,10 +4,11 @@
 Public names mirror /root/reference/stable_diffusion_videos/__init__.py:99-119 for the parts of the
 package that are on (or directly around) the walk path.
 """
+from .image_generation import generate_images
 from .pipeline import StableDiffusionPipelineOutput, StableDiffusionWalkPipeline
 from .scheduler import DDIMScheduler
 from .utils import get_timesteps_arr, make_video_pyav, pad_along_axis, slerp
 
 __version__ = "0.1.0"
 __all__ = ["StableDiffusionWalkPipeline", "StableDiffusionPipelineOutput", "DDIMScheduler", "slerp",
-           "get_timesteps_arr", "make_video_pyav", "pad_along_axis"]
+           "get_timesteps_arr", "make_video_pyav", "pad_along_axis", "generate_images"]

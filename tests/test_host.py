@@ -276,3 +276,48 @@ def test_hot_kernels_do_not_spill():
         assert names and len(names) == len(scratch)
         worst = max(zip(scratch, names))
         assert worst[0] <= limit, f"{name}: kernel {worst[1]} uses {worst[0]} B of scratch per lane (limit {limit})"
+
+
+def test_generate_images_layout_with_a_stub_pipeline(tmp_path):
+    """generate_images (reference image_generation.py:108-215): batching, ``{seed}{ext}`` file names, prompt_config.json
+    and the argument errors - exercised on CPU with a stub that has the pipeline's call shapes."""
+    import json
+    from types import SimpleNamespace
+    from PIL import Image
+    from stable_diffusion_videos_amd.image_generation import generate_images, generate_input_batches
+
+    class Stub:
+        device = torch.device("cpu")
+        tiled = False
+        unet = SimpleNamespace(in_channels=4)
+        scheduler = SimpleNamespace(config=SimpleNamespace(beta_start=0.00085, prediction_type="epsilon"))
+        calls = []
+
+        def embed_text(self, text):
+            return torch.zeros(1, 77, 8)
+
+        def init_noise(self, seed, shape):
+            return torch.full(shape, float(seed))
+
+        def __call__(self, text_embeddings=None, latents=None, output_type="pil", **kw):
+            self.calls.append((latents[:, 0, 0, 0].tolist(), kw["height"], output_type))
+            return {"images": [Image.new("RGB", (kw["width"], kw["height"])) for _ in range(latents.shape[0])]}
+
+    pipe = Stub()
+    files = generate_images(pipe, "a cat", batch_size=2, num_batches=2, seeds=[5, 6, 7, 8], output_dir=tmp_path, name="run",
+                            height=64, width=32, num_inference_steps=3, image_file_ext=".png")
+    assert [Path(f).name for f in files] == ["5.png", "6.png", "7.png", "8.png"] and all(Path(f).exists() for f in files)
+    assert pipe.calls == [([5.0, 6.0], 64, "pil"), ([7.0, 8.0], 64, "pil")]
+    cfg = json.loads((tmp_path / "run" / "prompt_config.json").read_text())
+    assert cfg["prompt"] == "a cat" and cfg["num_inference_steps"] == 3 and cfg["scheduler"]["prediction_type"] == "epsilon"
+    assert [b[1].shape[0] for b in generate_input_batches(pipe, ["p"] * 5, list(range(5)), 2, 64, 64)] == [2, 2, 1]
+    with pytest.raises(ValueError, match="seeds"):
+        generate_images(pipe, "a cat", batch_size=2, num_batches=1, seeds=[1], output_dir=tmp_path, name="bad")
+    with pytest.raises(ValueError, match="equal"):
+        list(generate_input_batches(pipe, ["a"], [1, 2], 1, 64, 64))
+    with pytest.raises(ValueError, match="repo_id"):
+        generate_images(pipe, "a cat", push_to_hub=True, output_dir=tmp_path, name="hub")
+    with pytest.raises(NotImplementedError):
+        generate_images(pipe, "a cat", push_to_hub=True, repo_id="x/y", output_dir=tmp_path, name="hub2")
+    with pytest.raises(FileExistsError):
+        generate_images(pipe, "a cat", seeds=[1], output_dir=tmp_path, name="run")

@@ -471,3 +471,26 @@ def test_clip_text_engine_full_size_vs_oracle(hip, dev):
     p = psnr(out, ref)
     report(f"clip text engine sd14 size vs oracle: PSNR {p:.1f} dB")
     assert p >= 38.0
+
+
+def test_generate_images_on_the_hip_path(hip, dev, tmp_path):
+    """generate_images (reference image_generation.py:108-215) end to end on the tiny pipeline, with and without the x4
+    generator; the same seed gives the same image as a direct __call__."""
+    from PIL import Image
+    from stable_diffusion_videos_amd import generate_images
+    from stable_diffusion_videos_amd.upsampling import RealESRGANModel
+    from stable_diffusion_videos_amd.weights import rrdbnet_shapes, synthetic_state_dict
+    pipe = _tiny_pipeline(dev)
+    files = generate_images(pipe, "a cat", batch_size=2, num_batches=2, seeds=[3, 4, 5, 6], output_dir=tmp_path, name="g",
+                            height=64, width=64, num_inference_steps=2, image_file_ext=".png")
+    assert [Path(f).name for f in files] == ["3.png", "4.png", "5.png", "6.png"]
+    direct = pipe(text_embeddings=pipe.embed_text("a cat"), latents=pipe.init_noise(5, (1, 4, 8, 8)), height=64, width=64,
+                  num_inference_steps=2, output_type="numpy_u8")["images"][0]
+    assert np.array_equal(np.asarray(Image.open(files[2])), direct)
+    up = RealESRGANModel(None)
+    up.cfg.num_block = 1
+    up.state_dict_ = synthetic_state_dict(rrdbnet_shapes(up.cfg), seed=1)
+    pipe.upsampler = up
+    big = generate_images(pipe, "a cat", seeds=[9], output_dir=tmp_path, name="u", height=64, width=64, num_inference_steps=2,
+                          image_file_ext=".png", upsample=True)
+    assert Image.open(big[0]).size == (256, 256)
