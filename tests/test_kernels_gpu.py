@@ -41,6 +41,24 @@ def test_gemm_dense(hip, dev, tile, M, N, K):
     assert rel_l2(out.float(), ref) < MFMA_TOL
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 6, 7, 9])
+def test_gemm_is_correctly_rounded(hip, dev, tile):
+    """Parity ladder step 2, element by element: against a float64 evaluation of the SAME bf16 inputs every
+    output must lie within half a bf16 ulp (the one rounding the kernel performs) plus fp32 accumulation noise
+    (1e-5 * sum |x_k w_k|; a CPU emulation of the kernel's arithmetic stays below 1e-6 of that sum).  This is ~100x tighter
+    than the rel-L2 bound of the other tests and catches any dropped / doubled K slice or misplaced fragment."""
+    M, N, K = 384, 640, 1280
+    x, w = rnd((M, K), dev, 11), rnd((N, K), dev, 12, K ** -0.5)
+    bias, res = rnd((N,), dev, 13), rnd((M, N), dev, 14)
+    xd, wd, bd, rd = x.double().cpu(), w.double().cpu(), bias.double().cpu(), res.double().cpu()
+    ref = xd @ wd.T + bd + rd
+    mag = xd.abs() @ wd.abs().T + bd.abs() + rd.abs()
+    out = hip.linear(x.to(BF16), w.to(BF16), bias, residual=res.to(BF16), tile=tile).float().cpu().double()
+    ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(ref.abs(), out.abs()).clamp_min(1e-30))) - 7)
+    ratio = (out - ref).abs() / (0.5 * ulp * (1 + 1e-3) + 1e-5 * mag)
+    assert float(ratio.max()) <= 1.0, f"tile {tile}: error {float(ratio.max()):.3f} x the rounding + accumulation bound"
+
+
 def test_gemm_asymmetric_identity(hip, dev):
     """A = I against an asymmetric B catches transposed / permuted fragment layouts exactly."""
     n = 256
