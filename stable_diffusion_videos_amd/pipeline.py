@@ -288,7 +288,10 @@ class StableDiffusionWalkPipeline:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # with a process group alive its watchdog thread may touch the runtime while this thread captures: only this
+            # thread's calls (kernel launches through the C ABI) need to be capture-safe
+            mode = "thread_local" if parallel.world()[1] > 1 else "global"
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 one_step()
             ent["graph"] = g
         self._graphs[key] = ent
