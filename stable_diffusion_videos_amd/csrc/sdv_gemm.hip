@@ -30,8 +30,13 @@ namespace {
 
 // waves per SIMD the register allocator must leave room for: the 32-wide-K tiles are meant to run two workgroups
 // per CU (16 waves -> 4 per SIMD -> <= 128 VGPRs)
-template <int WM, int WN, int TM, int TN, int BK, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) void igemm_kernel(const sdv_gemm_args p) {
+// NST = K-tile buffers in LDS.  2: double buffer, one `vmcnt(0)` + barrier per tile (the small / 64-wide-K tiles).
+// >2: a ring of NST 32-wide K tiles, NST-1 of them in flight by LDS-DMA ACROSS the barriers (counted `s_waitcnt vmcnt(N)`,
+// raw `s_barrier`): three tiles of loads per CU in flight keep HBM busy for the K <= 640 projections, the barrier sits in
+// the MIDDLE of a tile's MFMAs (fragments of the second k-step are already in registers), and the DMA issue and every
+// fragment read are slotted behind MFMAs instead of in front of them.
+template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST = 2>
+__global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * WM * WN / 4)) void igemm_kernel(const sdv_gemm_args p) {
     constexpr int NWV = WM * WN;            // waves per workgroup (4 or 8)
     // The extra activations (epi 3 LeakyReLU, 4 quick_gelu, 5 GELU: RRDBNet / CLIP text encoder) are compiled into the
     // 4-wave tiles only: the 8-wave 256x320 tile has no VGPRs to spare (adding them to its epilogue spilled 768 B of
@@ -266,15 +271,138 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
         }
     };
 
-    // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
     const int ntaps = CONV ? 9 : 1;
     const int nkt = (K / BK) * ntaps;
+    if constexpr (NST > 2) {
+        // ---- ring main loop ------------------------------------------------------------------------------
+        static_assert(KSTEPS == 2, "ring tiles are 32 wide in K");
+        constexpr int PER = NX + NW;   // LDS-DMA pieces EVERY wave issues per K tile (uniform, so the vmcnt counts are constants)
+        static_assert(GX % NWV == 0, "ring tiles: X panel pieces must divide evenly over the waves");
+        auto issue_pieces = [&](char* base) {
+            const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(base + (wave + NWV * i) * 1024),
+                                                         16, (int)xvo[i], kx, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                int g = wave + NWV * i;
+                unsigned off = wvo[i];
+                if (GW % NWV != 0 && i == NW - 1) {
+                    // surplus slot of the last round: repeat this wave's previous piece (same bytes to the same LDS address)
+                    const bool dup = g >= GW;
+                    g = dup ? g - NWV : g;
+                    off = dup ? wvo[i > 0 ? i - 1 : 0] : off;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024), 16,
+                                                         (int)off, kwb, 0, 0);
+            }
+        };
+        auto advance = [&]() {   // K-position bookkeeping of the piece stream (kept out of the MFMA blocks: it branches)
+            kx += ROWB;
+            kwb += ROWB;
+            if (--seg_left == 0) {
+                if (two_src && srcsel == 0) {
+                    srcsel = 1;
+                } else {
+                    srcsel = 0;
+                    ++tap;
+                }
+            }
+        };
+        auto issue_all = [&](char* base) {
+            if (seg_left == 0) new_segment();
+            issue_pieces(base);
+            advance();
+        };
+        // Wait until at most `ahead` K tiles of this wave's pieces are still in flight (VMEM returns in order, so the oldest
+        // tile has landed) AND this wave's fragment reads have returned (lgkmcnt): after the barrier that follows, the ring
+        // slot those reads came from is handed back to the LDS-DMA.
+        auto wait_stages = [&](int ahead) {
+            if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * PER) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        };
+        bf16x8_t fax[TM], faw[TN], fbx[TM], fbw[TN];
+        auto read_frags = [&](const char* base, int ks, bf16x8_t* xd, bf16x8_t* wd) {
+            const int lc = ks * 2 + lhi;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+        };
+        auto mfmas = [&](const bf16x8_t* xs, const bf16x8_t* ws) {
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[nt], xs[mt], acc[nt][mt], 0, 0, 0);
+        };
+        // prologue: fill the ring, wait for tile 0, fetch its first fragments
+        const int npre = nkt < NST ? nkt : NST;
+        for (int s = 0; s < npre; ++s) issue_all(smem + s * TILE_BYTES);
+        if (npre >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * PER) : "memory");
+        else wait_stages(npre - 1);
+        __builtin_amdgcn_s_barrier();
+        read_frags(smem, 0, fax, faw);
+        int cb = 0;   // ring slot of the tile being computed
+        // One K tile: [k-step 0 MFMAs || fragment reads of k-step 1] -> counted wait + barrier (tile kt+1 is now visible to
+        // every wave and nobody reads tile kt from LDS any more) -> [k-step 1 MFMAs || fragment reads of tile kt+1 ||
+        // LDS-DMA of tile kt+NST into the slot tile kt just left].
+        auto body = [&](auto ISSUE, auto NEXT, int ahead) {
+            constexpr bool issue = decltype(ISSUE)::value, next = decltype(NEXT)::value;
+            const char* cur = smem + cb * TILE_BYTES;
+            read_frags(cur, 1, fbx, fbw);
+            mfmas(fax, faw);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+            }
+            if constexpr (next) {
+                __builtin_amdgcn_sched_barrier(0);   // all k-step-0 MFMAs are issued before the wait: they cover the last reads
+                wait_stages(ahead);
+                __builtin_amdgcn_s_barrier();
+                const int nb = cb + 1 == NST ? 0 : cb + 1;
+                if constexpr (issue)
+                    if (seg_left == 0) new_segment();
+                read_frags(smem + nb * TILE_BYTES, 0, fax, faw);
+                if constexpr (issue) issue_pieces(smem + cb * TILE_BYTES);
+                mfmas(fbx, fbw);
+#pragma unroll
+                // (the LDS-DMA pieces write LDS, so the compiler keeps them behind the fragment reads: reads go behind the
+                //  first TM+TN MFMAs, the pieces are spread over the MFMAs that remain)
+                for (int i = 0; i < TM * TN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+                    if (i < TM + TN) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // 1 DS read
+                    } else if (issue) {
+                        constexpr int kGaps = TM * TN - (TM + TN) > 0 ? TM * TN - (TM + TN) : 1;
+                        const int j = i - (TM + TN);
+                        const int n = (PER * (j + 1)) / kGaps - (PER * j) / kGaps;
+#pragma unroll
+                        for (int q = 0; q < n; ++q) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // LDS-DMA pieces
+                    }
+                }
+                if constexpr (issue) advance();
+                cb = nb;
+            } else {
+                mfmas(fbx, fbw);
+            }
+        };
+        int kt = 0;
+        for (; kt + NST < nkt; ++kt) body(std::true_type{}, std::true_type{}, NST - 2);
+        for (; kt + 1 < nkt; ++kt) body(std::false_type{}, std::true_type{}, nkt - kt - 2);
+        body(std::false_type{}, std::false_type{}, 0);
+    } else {
+    // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
     stage(0);
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nkt) stage((kt + 1) & 1);
         compute(kt & 1);
+    }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
@@ -304,11 +432,16 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                 constexpr int CPO = OC / 8;                   // 16-byte bf16 chunks per output row
                 constexpr int ITERS = 32 * CPO / 64;
                 const int mbase = m0 + wm * TM * 32 + mt * 32;
+                // The swizzled slab addresses are 1-2 VALU each; opaque per-pass copies of the lane ids keep the compiler from
+                // hoisting all of them (16 registers) above the passes, where the 160 accumulator registers are still live
+                // (the 256 x 320 ring tile spilled 18 registers there).
+                int lane_p = lane, l31_p = l31;
+                asm volatile("" : "+v"(lane_p), "+v"(l31_p));
                 bf16x8_raw rres[ITERS];
                 if (R) {
 #pragma unroll
                     for (int it = 0; it < ITERS; ++it) {
-                        const int idx = lane + it * 64;
+                        const int idx = lane_p + it * 64;
                         const int r = idx / CPO, cj = idx % CPO;
                         const int m = mbase + r, n = ocol + cj * 8;
                         if (m < p.M && n < ncols_out) rres[it] = *(const bf16x8_raw*)(R + (long long)m * p.ldr + n);
@@ -336,7 +469,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                             o.z = (acc[nt][mt][4 * g + 2] * alpha + bv.z) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 2] * alpha + bg.z);
                             o.w = (acc[nt][mt][4 * g + 3] * alpha + bv.w) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 3] * alpha + bg.w);
                             const int chunk = j * 4 + 2 * g + lhi;
-                            *(float4*)(stg + l31 * 64 + ((chunk ^ (l31 & 7)) << 2)) = o;
+                            *(float4*)(stg + l31_p * 64 + ((chunk ^ (l31_p & 7)) << 2)) = o;
                         }
                 } else {
 #pragma unroll
@@ -359,12 +492,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
                             o.z = acc[nt][mt][4 * g4 + 2] * alpha + bv.z;
                             o.w = acc[nt][mt][4 * g4 + 3] * alpha + bv.w;
                             const int chunk = j * 8 + 2 * g4 + lhi;
-                            *(float4*)(stg + l31 * 64 + ((chunk ^ (l31 & 7)) << 2)) = o;
+                            *(float4*)(stg + l31_p * 64 + ((chunk ^ (l31_p & 7)) << 2)) = o;
                         }
                 }
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
-                    const int idx = lane + it * 64;
+                    const int idx = lane_p + it * 64;
                     const int r = idx / CPO, cj = idx % CPO;
                     const int m = mbase + r, n = ocol + cj * 8;
                     if (m < p.M && n < ncols_out) {
@@ -512,30 +645,30 @@ __global__ __launch_bounds__(WM * WN * 64, ((BK == 32 ? 2 : 1) * WM * WN / 4)) v
         }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, bool CONV>
+template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST>
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int TILES = 2 * (BM + BN) * BK * 2;
+    constexpr int TILES = NST * (BM + BN) * BK * 2;
     constexpr int STG = WM * WN * 32 * 64 * 4;                    // fp32 staging slabs of the epilogue
     constexpr int LDS = TILES > STG ? TILES : STG;
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, BK, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, BK, CONV, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS);
         attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV>), grid, dim3(WM * WN * 64), LDS, stream, a);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST>), grid, dim3(WM * WN * 64), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int BK>
+template <int WM, int WN, int TM, int TN, int BK, int NST = 2>
 int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
-    return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false>(a, stream)
-                       : launch_igemm_t<WM, WN, TM, TN, BK, true>(a, stream);
+    return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST>(a, stream)
+                       : launch_igemm_t<WM, WN, TM, TN, BK, true, NST>(a, stream);
 }
 
 }  // namespace
@@ -603,8 +736,9 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
             }
         }
     }
-    SDV_REQUIRE(!(a.epi >= 3 && tile >= 6 && tile <= 9), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
+    SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     switch (tile) {
+#ifndef SDV_GEMM_RING_ONLY   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
         case 1: return launch_igemm<2, 2, 2, 2, 64>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
         case 3: return launch_igemm<2, 2, 1, 1, 64>(a, s);    //  64 x  64
@@ -615,6 +749,9 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
         case 9: return launch_igemm<4, 2, 1, 5, 64>(a, s);    // 128 x 320, 8 waves
         case 10: return launch_igemm<4, 1, 2, 1, 64>(a, s);   // 256 x  32, 4 waves (RRDB growth convs, Cout = 32)
         case 11: return launch_igemm<4, 1, 2, 2, 64>(a, s);   // 256 x  64, 4 waves
+#endif
+        case 12: return launch_igemm<4, 2, 2, 5, 32, 4>(a, s);   // 256 x 320, 8 waves, ring of four 32-wide K tiles
+        case 13: return launch_igemm<4, 2, 2, 4, 32, 4>(a, s);   // 256 x 256, 8 waves, ring
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
     return SDV_OK;

@@ -24,7 +24,7 @@ def rnd(shape, dev, seed, scale=1.0):
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
-ALL_TILES = [1, 2, 3, 4, 6, 7, 8, 9, 10, 11]
+ALL_TILES = [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13]      # 12 / 13: the 4-slot LDS-ring tiles (counted vmcnt)
 
 
 @pytest.mark.parametrize("tile", ALL_TILES)
@@ -41,7 +41,7 @@ def test_gemm_dense(hip, dev, tile, M, N, K):
     assert rel_l2(out.float(), ref) < MFMA_TOL
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3, 6, 7, 9])
+@pytest.mark.parametrize("tile", [0, 1, 3, 6, 7, 9, 12, 13])
 def test_gemm_is_correctly_rounded(hip, dev, tile):
     """Parity ladder step 2, element by element: against a float64 evaluation of the SAME bf16 inputs every
     output must lie within half a bf16 ulp (the one rounding the kernel performs) plus fp32 accumulation noise
@@ -70,7 +70,7 @@ def test_gemm_asymmetric_identity(hip, dev):
         assert torch.equal(out.float(), w.T.contiguous()), f"tile {tile}"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13])
 def test_gemm_epilogues(hip, dev, tile):
     M, N, K = 384, 256, 192
     x, w = rnd((M, K), dev, 5), rnd((N, K), dev, 6, K ** -0.5)
@@ -89,7 +89,7 @@ def test_gemm_epilogues(hip, dev, tile):
     assert rel_l2(out.float(), x @ w.T + bias_n) < MFMA_TOL
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 12, 13])
 def test_gemm_geglu(hip, dev, tile):
     from stable_diffusion_videos_amd.weights import geglu_interleave
     M, Cc, K = 320, 128, 64          # proj: K -> 8*Cc... here value/gate halves of size 4*Cc = 512
@@ -140,7 +140,7 @@ def conv_ref(x_nhwc, w, bias, mode, circular):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 6, 9, 10, 11])
+@pytest.mark.parametrize("tile", [0, 1, 6, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("circular", [False, True])
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320),
@@ -168,7 +168,7 @@ def test_conv3x3_concat_residual_steptable(hip, dev):
     res = rnd((n, H, W, Cout), dev, 27)
     step = torch.tensor([3], dtype=torch.int32, device=dev)
     ref = conv_ref(torch.cat([x1, x2], -1), w, table[3], 1, False) + res
-    for tile in (0, 1, 2, 3, 6, 7, 8, 9):
+    for tile in (0, 1, 2, 3, 6, 7, 8, 9, 12, 13):
         out = hip.conv3x3(x1.reshape(-1, C1).to(BF16), conv_w(w, dev), table, nimg=n, H=H, W=W,
                           x2=x2.reshape(-1, C2).to(BF16), residual=res.reshape(-1, Cout).to(BF16), step_ptr=step,
                           bias_step_stride=Cout, tile=tile)

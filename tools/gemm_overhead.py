@@ -20,7 +20,7 @@ def bench(fn, reps=5):
 def main():
     dev = torch.device("cuda")
     M = 262144
-    for N, tile, epi in ((320, 6, 0), (2560, 7, 1), (2560, 7, 0), (320, 9, 0)):
+    for N, tile, epi in ((320, 6, 0), (320, 12, 0), (2560, 7, 1), (2560, 13, 1), (2560, 7, 0), (2560, 13, 0)):
         nout = N // 2 if epi == 1 else N
         out = torch.empty((M, nout), dtype=torch.bfloat16, device=dev)
         res = torch.randn((M, nout), device=dev).to(torch.bfloat16)
@@ -32,7 +32,7 @@ def main():
             t_bias = bench(lambda: hip.linear(x, w, bias, out=out, epi=epi, tile=tile))
             t_res = bench(lambda: hip.linear(x, w, bias, residual=res, out=out, epi=epi, tile=tile)) if epi != 1 else float("nan")
             bm = 256 if tile != 9 else 128
-            bn = {6: 320, 7: 256, 9: 320}[tile]
+            bn = {6: 320, 7: 256, 9: 320, 12: 320, 13: 256}[tile]
             rounds = ((M // bm) * (N // bn) + 255) // 256
             print(f"N={N} tile={tile} epi={epi} K={K:5d}: plain {t_plain:8.1f} us  +bias {t_bias:8.1f}  +bias+res {t_res:8.1f}"
                   f" | per round {t_plain / rounds:6.2f} us  TF(plain) {2.0 * M * N * K / t_plain / 1e6:7.1f}")
