@@ -22,6 +22,7 @@
 //     segments (16-B coalesced stores, residual loads prefetched before the pass).
 //   * Tiles: 8-wave 256x320 / 256x256 / 128x320 (UNet widths are multiples of 320), one workgroup per CU; small
 //     4-wave tiles for the low-resolution levels; chosen per launch by a measured cost model.  XCD-aware order.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "sdv_common.h"
@@ -70,8 +71,23 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int bm = tile_id % tiles_m;
-    const int bn = tile_id / tiles_m;
+    // Raster order inside an XCD's run: N is cut into strips of `gn` tiles and a strip is walked N-fastest, so the ~32
+    // workgroups an XCD runs at a time form a (32/gn) x gn block of output tiles - they stream 32/gn activation panels and
+    // gn weight panels through the XCD's 4 MiB L2 instead of 32 + 1 (M-fastest).  Measured with rocprofv3 FETCH_SIZE: the
+    // M-fastest order re-fetched every activation panel once per N tile from the fabric (profiles/round2_*).
+    const int tiles_n = nblk / tiles_m;
+    const int gn = p.tile > 0 ? (p.tile < tiles_n ? p.tile : tiles_n) : 1;
+    const int strip_sz = tiles_m * gn;
+    const int full = tiles_n / gn;
+    int strip = tile_id / strip_sz;
+    int gcols = gn;
+    if (strip >= full) {
+        strip = full;
+        gcols = tiles_n - full * gn;
+    }
+    const int rr = tile_id - strip * strip_sz;
+    const int bm = rr / gcols;
+    const int bn = strip * gn + (rr - bm * gcols);
     const int m0 = bm * BM;
     const int n0 = bn * BN;
     const long long bz = blockIdx.z;
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 int vy = xay[i] + dy, vx = xax[i] + dx;
-                if (p.circular) {
+                if (p.circular & 1) {
                     vy = vy < 0 ? vy + ext_y : (vy >= ext_y ? vy - ext_y : vy);
                     vx = vx < 0 ? vx + ext_x : (vx >= ext_x ? vx - ext_x : vx);
                 }
@@ -526,7 +542,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                                 for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
                             }
                         }
-                        *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
+                        if (p.circular & 2) {   // EXPERIMENT (SDV_GEMM_NT=1): streaming stores
+                            const bf16x8_raw v = pack8(f);
+                            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(C + (long long)m * p.ldc + n));
+                        } else {
+                            *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
+                        }
                     }
                 }
             };
@@ -710,6 +731,8 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     if (a.bias_mode == 0 && a.bias) a.bias_mode = 1;
     if (a.alpha == 0.f) a.alpha = 1.f;
     hipStream_t s = (hipStream_t)stream;
+    const int nt_env = getenv("SDV_GEMM_NT") ? atoi(getenv("SDV_GEMM_NT")) : 0;
+    a.circular = (a.circular ? 1 : 0) | (nt_env ? 2 : 0);
     int tile = a.tile;
     const long long nb = a.batch > 0 ? a.batch : 1;
     auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nb; };
@@ -736,6 +759,8 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
             }
         }
     }
+    const int gn_env = getenv("SDV_GEMM_GN") ? atoi(getenv("SDV_GEMM_GN")) : 4;   // EXPERIMENT knob (re-read per call)
+    a.tile = gn_env;   // the kernel reads `tile` as the raster strip width (N tiles per strip)
     SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     switch (tile) {
 #ifndef SDV_GEMM_RING_ONLY   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
