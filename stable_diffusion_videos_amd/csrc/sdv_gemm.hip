@@ -22,7 +22,6 @@
 //     segments (16-B coalesced stores, residual loads prefetched before the pass).
 //   * Tiles: 8-wave 256x320 / 256x256 / 128x320 (UNet widths are multiples of 320), one workgroup per CU; small
 //     4-wave tiles for the low-resolution levels; chosen per launch by a measured cost model.  XCD-aware order.
-#include <stdlib.h>
 #include <type_traits>
 
 #include "sdv_common.h"
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 int vy = xay[i] + dy, vx = xax[i] + dx;
-                if (p.circular & 1) {
+                if (p.circular) {
                     vy = vy < 0 ? vy + ext_y : (vy >= ext_y ? vy - ext_y : vy);
                     vx = vx < 0 ? vx + ext_x : (vx >= ext_x ? vx - ext_x : vx);
                 }
@@ -542,12 +541,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                                 for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
                             }
                         }
-                        if (p.circular & 2) {   // EXPERIMENT (SDV_GEMM_NT=1): streaming stores
-                            const bf16x8_raw v = pack8(f);
-                            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(C + (long long)m * p.ldc + n));
-                        } else {
-                            *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
-                        }
+                        *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
                     }
                 }
             };
@@ -731,8 +725,6 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     if (a.bias_mode == 0 && a.bias) a.bias_mode = 1;
     if (a.alpha == 0.f) a.alpha = 1.f;
     hipStream_t s = (hipStream_t)stream;
-    const int nt_env = getenv("SDV_GEMM_NT") ? atoi(getenv("SDV_GEMM_NT")) : 0;
-    a.circular = (a.circular ? 1 : 0) | (nt_env ? 2 : 0);
     int tile = a.tile;
     const long long nb = a.batch > 0 ? a.batch : 1;
     auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nb; };
@@ -759,8 +751,8 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
             }
         }
     }
-    const int gn_env = getenv("SDV_GEMM_GN") ? atoi(getenv("SDV_GEMM_GN")) : 4;   // EXPERIMENT knob (re-read per call)
-    a.tile = gn_env;   // the kernel reads `tile` as the raster strip width (N tiles per strip)
+    a.tile = 4;   // the kernel reads `tile` as the raster strip width: 8 x 4 blocks of output tiles per XCD wave (1 / 2 / 4 / 8
+                  // measured on the UNet: 120.2 / 118.5 / 118.1 / 118.0 ms per forward, profiles/round2_raster_order.txt)
     SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     switch (tile) {
 #ifndef SDV_GEMM_RING_ONLY   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
