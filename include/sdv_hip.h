@@ -47,6 +47,10 @@ int sdv_abi_version(void);
  *
  * mode      0 dense rows; 1 conv3x3 stride 1 pad 1; 2 conv3x3 stride 2 pad 1;
  *           3 nearest-2x upsample followed by conv3x3 pad 1 (Upsample2D), gathered on the fly.
+ *           4 the same op in phase form: output pixel (2y+py, 2x+px) only sees the 2 x 2 low-resolution pixels
+ *             {y-1+py, y+py} x {x-1+px, x+px}, so the 3x3 filter collapses to four 2x2 filters (taps that hit the same
+ *             source pixel are summed by the caller) - 4/9 of the multiplies.  W is [4 phases][N][2][2][Cin], ldw = 4*Cin,
+ *             Hin = Hout = H, Win = Wout = W (LOW-resolution grid), M = nimg*H*W, C is the [nimg*2H*2W][ldc] output.
  *           For conv modes M = nimg*Hout*Wout, K = Cin and W is [N][3][3][Cin] (OHWI), ldw = 9*Cin.
  * X2/C1     optional second source: channels [0,C1) come from X, [C1,K) from X2 (skip-connection
  *           concat without materialising it).  C1 % 64 == 0.
@@ -75,8 +79,9 @@ typedef struct sdv_gemm_args {
     int32_t mode, Hin, Win, Hout, Wout, circular;
     int32_t epi, bias_mode, bias_step_stride;
     int32_t batch;
-    int32_t tile;    /* 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 256x32, 11 = 256x64 (4 waves) */
+    int32_t tile;    /* 12 = 256x320, 13 = 256x256 as a ring of four 32-wide K tiles (counted vmcnt); 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 256x32, 11 = 256x64 (4 waves) */
     float alpha;
+    uint32_t div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;   /* filled in by sdv_gemm_bf16 (mode 4 row mapping); callers leave 0 */
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);

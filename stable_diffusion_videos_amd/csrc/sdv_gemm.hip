@@ -158,8 +158,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     auto new_segment = [&]() {
         const int ld2 = 2 * (srcsel ? p.ldx2 : p.ldx);
         if constexpr (CONV) {
-            const int dy = tap / 3 - 1;
-            const int dx = tap - (tap / 3) * 3 - 1;
+            // mode 4 (one phase (py, px) = blockIdx.z of a nearest-2x-upsample + conv3x3, see sdv_hip.h): 2 x 2 taps on the
+            // low-resolution grid, rows {y-1+py, y+py}, columns {x-1+px, x+px}
+            const int dy = p.mode == 4 ? (tap >> 1) - 1 + (int)(bz >> 1) : tap / 3 - 1;
+            const int dx = p.mode == 4 ? (tap & 1) - 1 + (int)(bz & 1) : tap - (tap / 3) * 3 - 1;
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 int vy = xay[i] + dy, vx = xax[i] + dx;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         }
     };
 
-    const int ntaps = CONV ? 9 : 1;
+    const int ntaps = CONV ? (p.mode == 4 ? 4 : 9) : 1;
     const int nkt = (K / BK) * ntaps;
     if constexpr (NST > 2) {
         // ---- ring main loop ------------------------------------------------------------------------------
@@ -426,6 +428,18 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     if (bias && p.step_ptr) bias += (long long)(*p.step_ptr) * p.bias_step_stride;
     uint16_t* __restrict__ C = p.C + bz * p.sC;
     const uint16_t* __restrict__ R = p.R ? p.R + bz * p.sR : nullptr;
+    // output row of GEMM row m: m itself, except for mode 4 where low-resolution pixel (img, y, x) of phase (py, px) lands on
+    // pixel (2y+py, 2x+px) of the 2x image (divisions by host-made magic numbers: exact for m < 2^31)
+    auto out_row = [&](int m) -> long long {
+        if constexpr (!CONV) return m;
+        if (p.mode != 4) return m;
+        const unsigned um = (unsigned)m;
+        const unsigned img = p.div_hw_mul ? __umulhi(um, p.div_hw_mul) >> p.div_hw_shr : um >> p.div_hw_shr;
+        const unsigned rem = um - img * (unsigned)(p.Hout * p.Wout);
+        const unsigned y = p.div_w_mul ? __umulhi(rem, p.div_w_mul) >> p.div_w_shr : rem >> p.div_w_shr;
+        const unsigned x = rem - y * (unsigned)p.Wout;
+        return ((long long)img * (2 * p.Hout) + (2 * y + (unsigned)(bz >> 1))) * (2 * p.Wout) + (2 * x + (unsigned)(bz & 1));
+    };
     const bool geglu = p.epi == 1;
     const int wcol0 = n0 + wn * TN * 32;  // first (permuted, for GEGLU) weight row of this wave
 
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         const int idx = lane_p + it * 64;
                         const int r = idx / CPO, cj = idx % CPO;
                         const int m = mbase + r, n = ocol + cj * 8;
-                        if (m < p.M && n < ncols_out) rres[it] = *(const bf16x8_raw*)(R + (long long)m * p.ldr + n);
+                        if (m < p.M && n < ncols_out) rres[it] = *(const bf16x8_raw*)(R + out_row(m) * p.ldr + n);
                     }
                 }
                 const int mrow = mbase + l31;
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                                 for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
                             }
                         }
-                        *(bf16x8_raw*)(C + (long long)m * p.ldc + n) = pack8(f);
+                        *(bf16x8_raw*)(C + out_row(m) * p.ldc + n) = pack8(f);
                     }
                 }
             };
@@ -694,7 +708,7 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     SDV_REQUIRE(a.X && a.W && a.C, "sdv_gemm_bf16: null operand");
     SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SDV_REQUIRE(a.K % 64 == 0, "sdv_gemm_bf16: K=%d must be a multiple of 64", a.K);
-    SDV_REQUIRE(a.mode >= 0 && a.mode <= 3, "sdv_gemm_bf16: bad mode %d", a.mode);
+    SDV_REQUIRE(a.mode >= 0 && a.mode <= 4, "sdv_gemm_bf16: bad mode %d", a.mode);
     SDV_REQUIRE(a.epi >= 0 && a.epi <= 5, "sdv_gemm_bf16: bad epi %d", a.epi);
     if (!a.X2) {
         a.C1 = a.K;
@@ -706,11 +720,35 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     if (a.mode != 0) {
         SDV_REQUIRE(a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "sdv_gemm_bf16: bad conv geometry");
         SDV_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "sdv_gemm_bf16: M must be nimg*Hout*Wout");
-        SDV_REQUIRE(a.ldw >= 9 * a.K, "sdv_gemm_bf16: conv weights must be [N][3][3][K]");
+        SDV_REQUIRE(a.ldw >= (a.mode == 4 ? 4 : 9) * a.K, "sdv_gemm_bf16: conv weights must be [N][3][3][K]");
         SDV_REQUIRE(a.batch <= 1, "sdv_gemm_bf16: conv modes are not batched");
         if (a.mode == 1) SDV_REQUIRE(a.Hin == a.Hout && a.Win == a.Wout, "conv s1 geometry");
         if (a.mode == 2) SDV_REQUIRE(a.Hout == (a.Hin + 1) / 2 && a.Wout == (a.Win + 1) / 2, "conv s2 geometry");
         if (a.mode == 3) SDV_REQUIRE(a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win, "upsample-conv geometry");
+        if (a.mode == 4) {
+            SDV_REQUIRE(a.Hin == a.Hout && a.Win == a.Wout, "phase upsample-conv: Hout/Wout are the LOW-resolution grid");
+            SDV_REQUIRE(a.ldw >= 4 * a.K, "sdv_gemm_bf16: phase upsample-conv weights must be [4][N][2][2][K]");
+            SDV_REQUIRE(!a.R && a.epi != 1 && (a.ldc & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.C) & 15) == 0,
+                        "sdv_gemm_bf16: phase upsample-conv needs the aligned epilogue (no residual / GEGLU)");
+            a.batch = 4;                                  // blockIdx.z = phase (py, px)
+            a.sX = 0;
+            a.sC = 0;
+            a.sR = 0;
+            a.sW = (long long)a.N * a.ldw;
+            auto magic = [](unsigned d, unsigned* mul, unsigned* shr) {   // n / d == umulhi(n, mul) >> shr for n < 2^31
+                unsigned s = 0;
+                while ((2u << s) <= d) ++s;               // s = floor(log2 d)
+                if ((1u << s) == d) {
+                    *mul = 0;
+                    *shr = s;
+                } else {
+                    *mul = (unsigned)((((unsigned long long)1 << (32 + s)) + d - 1) / d);
+                    *shr = s;
+                }
+            };
+            magic((unsigned)(a.Hout * a.Wout), &a.div_hw_mul, &a.div_hw_shr);
+            magic((unsigned)a.Wout, &a.div_w_mul, &a.div_w_shr);
+        }
         // 31-bit lane offsets inside the workgroup's window (a 320-row tile spans at most 320/HWout + 2 images)
         const long long win = ((long long)(320 / (a.Hout * a.Wout)) + 2) * a.Hin * a.Win * (a.ldx > a.ldx2 ? a.ldx : a.ldx2) * 2;
         SDV_REQUIRE(win < 0x7fffffffLL, "sdv_gemm_bf16: conv window too large for 31-bit offsets");

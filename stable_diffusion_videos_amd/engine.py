@@ -23,7 +23,7 @@ import torch
 
 from . import hip
 from .config import UNetConfig, VAEConfig
-from .weights import StateDict, conv_w, conv_w_c4, geglu_interleave, lin_w, vec
+from .weights import StateDict, conv_w, conv_w_c4, geglu_interleave, lin_w, upconv_phase_w, vec
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -221,7 +221,7 @@ class UNetEngine:
                 if typ.startswith("CrossAttn"):
                     blk["attn"].append(tfm(f"up_blocks.{i}.attentions.{j}", len(ch) - 1 - i))
             if i != len(ch) - 1:
-                blk["up"] = (conv_w(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"], dev),
+                blk["up"] = (upconv_phase_w(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"], dev),
                              vec(sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], dev))
             self.up.append(blk)
         self.out_g, self.out_b = vec(sd["conv_norm_out.weight"], dev), vec(sd["conv_norm_out.bias"], dev)
@@ -321,7 +321,7 @@ class UNetEngine:
                     h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww))
             if blk["up"] is not None:
                 wu, bu = blk["up"]
-                h = hip.conv3x3(h, wu, bu, nimg=nimg, H=hh, W=ww, mode=3, circular=circ)
+                h = hip.upconv3x3_phase(h, wu, bu, nimg=nimg, H=hh, W=ww, circular=circ)      # Upsample2D: nearest 2x + conv
                 hh, ww = 2 * hh, 2 * ww
         h = hip.groupnorm(h, self.out_g, self.out_b, nimg=nimg, HW=hh * ww, groups=self.groups, eps=self.eps, silu=True)
         eps = torch.empty((nimg, hh, ww, self.cfg.out_channels), dtype=F32, device=self.device)
@@ -360,7 +360,7 @@ class VAEDecoderEngine:
             blk = {"res": [_Res(sd, f"decoder.up_blocks.{i}.resnets.{j}", dev, g, 1e-6, False)
                            for j in range(cfg.layers_per_block + 1)], "up": None}
             if i != len(ch) - 1:
-                blk["up"] = (conv_w(sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"], dev),
+                blk["up"] = (upconv_phase_w(sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"], dev),
                              vec(sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"], dev))
             self.up.append(blk)
         self.out_g, self.out_b = vec(sd["decoder.conv_norm_out.weight"], dev), vec(sd["decoder.conv_norm_out.bias"], dev)
@@ -400,7 +400,7 @@ class VAEDecoderEngine:
                 x = r(x, None, B, h, w, None, circ)
             if blk["up"] is not None:
                 wu, bu = blk["up"]
-                x = hip.conv3x3(x, wu, bu, nimg=B, H=h, W=w, mode=3, circular=circ)
+                x = hip.upconv3x3_phase(x, wu, bu, nimg=B, H=h, W=w, circular=circ)
                 h, w = 2 * h, 2 * w
         x = hip.groupnorm(x, self.out_g, self.out_b, nimg=B, HW=h * w, groups=self.groups, eps=1e-6, silu=True)
         oc = self.cfg.out_channels

@@ -34,7 +34,11 @@ class GemmArgs(C.Structure):
         ("circular", C.c_int32),
         ("epi", C.c_int32), ("bias_mode", C.c_int32), ("bias_step_stride", C.c_int32),
         ("batch", C.c_int32), ("tile", C.c_int32), ("alpha", C.c_float),
+        ("div_hw_mul", C.c_uint32), ("div_hw_shr", C.c_uint32), ("div_w_mul", C.c_uint32), ("div_w_shr", C.c_uint32),
     ]
+
+
+ABI_VERSION = 4     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -93,6 +97,9 @@ def load(build_if_missing: bool = False):
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.sdv_abi_version() != ABI_VERSION:
+        raise SdvHipError(f"{_LIB_PATH} reports ABI version {lib.sdv_abi_version()}, this binding needs {ABI_VERSION}: "
+                          "rebuild it with `python -m stable_diffusion_videos_amd.build --force`")
     _lib = lib
     return lib
 
@@ -170,8 +177,11 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     a.epi, a.bias_mode, a.bias_step_stride = epi, (bias_mode if bias is not None else 0), bias_step_stride
     a.batch, a.tile, a.alpha = batch, tile, alpha
     taps = 1 if mode == 0 else 9
+    # algorithmic work: the phase form (mode 4) is a nearest-2x upsample + conv3x3 on 4*M output pixels (9 taps each);
+    # it EXECUTES 4 taps per output pixel
+    flops = 2.0 * M * N * K * taps * (4 if mode == 4 else batch)
     _launch("gemm" if mode == 0 else "conv3x3",
-            dict(M=M, N=N, K=K * taps, batch=batch, flops=2.0 * M * N * K * taps * batch, mode=mode, epi=epi),
+            dict(M=M * (4 if mode == 4 else 1), N=N, K=K * taps, batch=batch, flops=flops, mode=mode, epi=epi),
             lambda: _check(lib.sdv_gemm_bf16(C.byref(a), _stream()), "sdv_gemm_bf16"))
 
 
@@ -206,6 +216,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
     Cout = w.shape[0]
     if w.shape[1] != 9 * (C1 + C2):
         raise SdvHipError(f"conv3x3: weight K {w.shape[1]} != 9*{C1 + C2}")
+    if mode == 4:
+        return upconv3x3_phase(x, w, bias, nimg=nimg, H=H, W=W, circular=circular, out=out, tile=tile)
     if mode == 1:
         Ho, Wo = H, W
     elif mode == 2:
@@ -220,6 +232,21 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
          C1=C1 if x2 is not None else 0, ldx2=x2.stride(0) if x2 is not None else 0, mode=mode, Hin=H, Win=W,
          Hout=Ho, Wout=Wo, circular=circular, step_ptr=step_ptr, bias_step_stride=bias_step_stride, tile=tile,
          epi=epi, alpha=alpha)
+    return out
+
+
+def upconv3x3_phase(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor], *, nimg: int, H: int, W: int,
+                    circular: bool = False, out=None, tile: int = 0) -> torch.Tensor:
+    """Upsample2D (nearest 2x, then conv3x3 pad 1) in phase form: x [nimg*H*W, Cin] -> [nimg*2H*2W, Cout].
+    ``w4``: [4*Cout, 4*Cin] from ``weights.upconv_phase_w`` (phase-major; 2x2 taps with the coincident 3x3 taps summed)."""
+    Cin = x.shape[1]
+    if w4.shape[0] % 4 or w4.shape[1] != 4 * Cin:
+        raise SdvHipError(f"upconv3x3_phase: weight shape {tuple(w4.shape)} does not match Cin={Cin}")
+    Cout = w4.shape[0] // 4
+    if out is None:
+        out = torch.empty((nimg * 4 * H * W, Cout), dtype=BF16, device=x.device)
+    gemm(x, w4, out, M=nimg * H * W, N=Cout, K=Cin, ldx=x.stride(0), ldw=w4.stride(0), ldc=out.stride(0), bias=bias, mode=4,
+         Hin=H, Win=W, Hout=H, Wout=W, circular=circular, tile=tile)
     return out
 
 

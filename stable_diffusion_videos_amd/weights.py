@@ -292,6 +292,24 @@ def conv_w(w: torch.Tensor, device) -> torch.Tensor:
     return w.permute(0, 2, 3, 1).reshape(co, -1).contiguous().to(device=device, dtype=torch.bfloat16)
 
 
+def upconv_phase_w(w: torch.Tensor, device) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] filter of ``Upsample2D`` (nearest 2x, then conv3x3 pad 1) -> [4*Cout, 4*Cin] bf16: one 2x2 filter
+    per output phase (py, px), phase-major, each OHWI.  Output pixel (2y+py, 2x+px) reads the upsampled rows 2y+py+dy
+    (dy = -1, 0, 1) = low-resolution rows floor(.../2): {y-1, y, y} for py = 0 and {y, y, y+1} for py = 1, so the 3x3 taps
+    that land on the same low-resolution pixel are summed (in fp32, then rounded to bf16 once): the result equals the 9-tap
+    conv on the materialised 2x image up to that one weight rounding, with 4/9 of the multiplies."""
+    co, ci = w.shape[:2]
+    wf = w.to(torch.float32)
+    groups = {0: ([0], [1, 2]), 1: ([0, 1], [2])}          # phase -> 3x3 tap indices summed into 2x2 tap 0 / tap 1
+    out = torch.empty((2, 2, co, 2, 2, ci), dtype=torch.float32)
+    for py in (0, 1):
+        for px in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    out[py, px, :, ty, tx, :] = wf[:, :, groups[py][ty], :][:, :, :, groups[px][tx]].sum(dim=(2, 3))
+    return out.reshape(4 * co, 4 * ci).contiguous().to(device=device, dtype=torch.bfloat16)
+
+
 def conv_w_c4(w: torch.Tensor, device) -> torch.Tensor:
     """[Cout, 4, 3, 3] -> [Cout, 64]: OHWI rows (tap-major, 36 values) zero-padded to one 64-wide K tile, the layout
     ``sdv_im2col3x3_c4`` produces for the activations."""

@@ -21,7 +21,7 @@ def test_c_abi_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libsdv_hip.so does not export {name}"
     assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip.load().sdv_abi_version() == 3
+    assert hip.load().sdv_abi_version() == hip.ABI_VERSION == 4
 
 
 def test_gemm_args_struct_matches_header(hip):
@@ -96,6 +96,35 @@ def test_weight_schema_and_relayout():
     g = weights.geglu_interleave(t)
     assert g[:16, 0].tolist() == list(range(0, 16)) and g[16:32, 0].tolist() == list(range(64, 80))
     assert g[32:48, 0].tolist() == list(range(16, 32)) and g[48:64, 0].tolist() == list(range(80, 96))
+
+
+def test_upconv_phase_weights_reproduce_upsample_conv():
+    """weights.upconv_phase_w: the four 2x2 phase filters applied to the LOW-resolution image equal nearest-2x upsampling
+    followed by the 3x3 conv (reference: diffusers Upsample2D inside unet(...) / vae.decode(...),
+    stable_diffusion_pipeline.py:418, :433) - checked in fp64 with plain torch ops."""
+    import torch.nn.functional as F
+    from stable_diffusion_videos_amd.weights import upconv_phase_w
+    g = torch.Generator().manual_seed(0)
+    co, ci, H, W = 6, 5, 7, 9
+    w = torch.randn((co, ci, 3, 3), generator=g, dtype=torch.float64)
+    x = torch.randn((2, ci, H, W), generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    w4 = upconv_phase_w(w, "cpu").to(torch.float64).reshape(2, 2, co, 2, 2, ci)         # bf16-rounded phase filters
+    w4x = torch.empty_like(w4)                                                           # exact (unrounded) phase filters
+    groups = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    for py in (0, 1):
+        for px in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    w4x[py, px, :, ty, tx, :] = w[:, :, groups[py][ty], :][:, :, :, groups[px][tx]].sum(dim=(2, 3))
+    xp = F.pad(x, (1, 1, 1, 1))
+    for filt, tol in ((w4x, 1e-12), (w4, 2e-2)):
+        out = torch.empty_like(ref)
+        for py in (0, 1):
+            for px in (0, 1):
+                k = filt[py, px].permute(0, 3, 1, 2)                                      # [co, ci, 2, 2]
+                out[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + H + 1, px:px + W + 1], k)
+        assert float((out - ref).abs().max()) <= tol * float(ref.abs().max())
 
 
 def test_scheduler_coefficients_equal_oracle_step():

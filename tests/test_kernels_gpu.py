@@ -158,6 +158,27 @@ def test_conv3x3(hip, dev, tile, mode, circular, n, H, W, Cin, Cout):
     assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL
 
 
+@pytest.mark.parametrize("tile", [0, 1, 6, 9, 12])
+@pytest.mark.parametrize("circular", [False, True])
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320), (1, 6, 10, 64, 40)])
+def test_upconv_phase_form(hip, dev, tile, circular, n, H, W, Cin, Cout):
+    """Upsample2D (nearest 2x + conv3x3) as four 2x2 phase filters (sdv_gemm_bf16 mode 4, 4/9 of the multiplies) against the
+    fp32 F.interpolate + F.conv2d reference and against the gather-on-the-fly 9-tap kernel (mode 3).  The phase filters sum
+    coincident taps in fp32 and round ONCE to bf16: a few e-4 of extra relative error, inside the MFMA tolerance."""
+    from stable_diffusion_videos_amd.weights import conv_w, upconv_phase_w
+    x = rnd((n, H, W, Cin), dev, 30)
+    w = rnd((Cout, Cin, 3, 3), dev, 31, (9 * Cin) ** -0.5)
+    bias = rnd((Cout,), dev, 32)
+    ref = conv_ref(x, w, bias, 3, circular)
+    out = hip.upconv3x3_phase(x.reshape(-1, Cin).to(BF16), upconv_phase_w(w.cpu(), dev), bias, nimg=n, H=H, W=W,
+                              circular=circular, tile=tile)
+    torch.cuda.synchronize()
+    assert out.shape == (n * 4 * H * W, Cout)
+    assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL
+    nine = hip.conv3x3(x.reshape(-1, Cin).to(BF16), conv_w(w, dev), bias, nimg=n, H=H, W=W, mode=3, circular=circular)
+    assert rel_l2(out.float(), nine.float()) < MFMA_TOL
+
+
 def test_conv3x3_concat_residual_steptable(hip, dev):
     """ResBlock conv forms: two-source channel concat, residual add, per-step bias table."""
     from stable_diffusion_videos_amd.weights import conv_w
