@@ -158,6 +158,32 @@ def test_conv3x3(hip, dev, tile, mode, circular, n, H, W, Cin, Cout):
     assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL
 
 
+def _half_ulp_ratio(out64, ref64, mag64, acc_eps=1e-5):
+    """|out - ref| relative to (half a bf16 ulp of the result + fp32 accumulation noise acc_eps * sum |terms|)."""
+    ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(ref64.abs(), out64.abs()).clamp_min(1e-30))) - 7)
+    return (out64 - ref64).abs() / (0.5 * ulp * (1 + 1e-3) + acc_eps * mag64)
+
+
+@pytest.mark.parametrize("tile,mode", [(0, 1), (6, 1), (1, 1), (12, 1), (0, 2), (0, 3)])
+def test_conv3x3_is_correctly_rounded(hip, dev, tile, mode):
+    """Parity ladder step 2 for the implicit-GEMM conv on the UNet's real 64x64-level shape (320 -> 320 channels, 64 x 64
+    pixels, 2 images): EVERY output pixel within half a bf16 ulp + fp32 accumulation noise of a float64 convolution of the
+    same bf16 inputs - a wrong halo pixel, a dropped tap or a swapped K tile in one corner of one tile fails it (a rel-L2
+    gate does not see a single bad pixel among 2.6 M outputs)."""
+    from stable_diffusion_videos_amd.weights import conv_w
+    n, H, W, Cin, Cout = 2, 64, 64, 320, 320
+    x = rnd((n, H, W, Cin), dev, 60)
+    w = rnd((Cout, Cin, 3, 3), dev, 61, (9 * Cin) ** -0.5)
+    bias = rnd((Cout,), dev, 62)
+    xd, wd, bd = x.double().cpu(), w.double().cpu(), bias.double().cpu()
+    ref = conv_ref(xd, wd, bd, mode, False)
+    mag = conv_ref(xd.abs(), wd.abs(), bd.abs(), mode, False)
+    out = hip.conv3x3(x.reshape(-1, Cin).to(BF16), conv_w(w, dev), bias, nimg=n, H=H, W=W, mode=mode, tile=tile)
+    torch.cuda.synchronize()
+    ratio = _half_ulp_ratio(out.double().cpu().reshape(ref.shape), ref, mag)
+    assert float(ratio.max()) <= 1.0, f"tile {tile} mode {mode}: {float(ratio.max()):.3f} x the rounding + accumulation bound"
+
+
 @pytest.mark.parametrize("tile", [0, 1, 6, 9, 12])
 @pytest.mark.parametrize("circular", [False, True])
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320), (1, 6, 10, 64, 40)])
@@ -327,6 +353,57 @@ def test_attention(hip, dev, dh, Lq, Lk):
                   ldk=Cc, ldv=ldv, ldo=Cc, scale=scale)
     torch.cuda.synchronize()
     assert rel_l2(out.float().view(B, Lq, Cc), ref) < 6e-3
+
+
+def _attn_ref64(q, k, v, heads, scale):
+    """float64 softmax(QK^T scale) V per head, plus sum_k p_k |v_k| (the scale of the P-rounding error)."""
+    B, Lq, Cc = q.shape
+    dh = Cc // heads
+    out = torch.empty((B, Lq, Cc), dtype=torch.float64)
+    mag = torch.empty_like(out)
+    for b in range(B):
+        for h in range(heads):
+            sl = slice(h * dh, (h + 1) * dh)
+            p = torch.softmax(q[b, :, sl] @ k[b, :, sl].T * scale, -1)
+            out[b, :, sl] = p @ v[b, :, sl]
+            mag[b, :, sl] = p @ v[b, :, sl].abs()
+    return out, mag
+
+
+@pytest.mark.parametrize("dh,Lq,Lk,qscale", [(40, 4096, 4096, 1.0), (40, 4096, 4096, 5.0), (40, 4096, 77, 1.0), (80, 1024, 1024, 1.0),
+                                             (80, 1024, 1024, 5.0), (160, 256, 256, 1.0), (64, 1024, 1024, 5.0)])
+def test_attention_elementwise_bound(hip, dev, dh, Lq, Lk, qscale):
+    """Element-by-element bound against a float64 softmax(QK^T)V of the same bf16 inputs, on the UNet's real attention
+    shapes (64 x 64 level: dh 40, 4096 tokens; cross-attention: 77 keys).  The kernel rounds P to bf16 before the PV MFMA
+    (and, for the 40 / 80-wide heads, the pre-scaled Q), so the bound is half a bf16 ulp of the output plus
+    2^-6 * sum_k p_k |v_k| (measured worst case 0.3 - 0.5 of that on MI355X) - a dropped or doubled key tile moves an
+    output by ~1/64 of sum p |v| per tile at these sizes and fails it, which the 6e-3 rel-L2 gate cannot see.  The
+    channel pattern of V makes every key tile visible: channel d of V is 1 on the keys of tile d (mod dh) and random noise
+    elsewhere.  qscale = 5 multiplies Q so that the logits have the spread of a TRAINED model's self-attention (std ~5
+    instead of ~1): the running max then jumps by more than the deferral threshold in most tiles and the O-rescale branch
+    runs all the time instead of never."""
+    B, heads = 1, 8
+    Cc = heads * dh
+    q, k = rnd((B, Lq, Cc), dev, 70, qscale), rnd((B, Lk, Cc), dev, 71)
+    v = rnd((B, Lk, Cc), dev, 72, 0.25)
+    tile_of_key = (torch.arange(Lk, device=dev) // 64) % dh
+    for h in range(heads):
+        v[0, torch.arange(Lk, device=dev), h * dh + tile_of_key] = 1.0
+    scale = dh ** -0.5
+    ref, mag = _attn_ref64(q.double().cpu(), k.double().cpu(), v.double().cpu(), heads, scale)
+    ldv = (Lk + 63) // 64 * 64
+    vt = torch.zeros((B, Cc, ldv), dtype=BF16, device=dev)
+    vt[:, :, :Lk] = v.transpose(1, 2).to(BF16)
+    out = torch.empty((B * Lq, Cc), dtype=BF16, device=dev)
+    hip.attention(q.reshape(-1, Cc).to(BF16), k.reshape(-1, Cc).to(BF16), vt, out, B=B, H=heads, Lq=Lq, Lk=Lk, dh=dh, ldq=Cc,
+                  ldk=Cc, ldv=ldv, ldo=Cc, scale=scale)
+    torch.cuda.synchronize()
+    o64 = out.double().cpu().view(B, Lq, Cc)
+    ratio = _half_ulp_ratio(o64, ref, mag, acc_eps=2.0 ** -6)
+    from conftest import report
+    report(f"attention dh={dh} Lq={Lq} Lk={Lk} qscale={qscale}: worst element at {float(ratio.max()):.3f} of (half ulp + 2^-6 sum p|v|), "
+           f"rel-L2 {rel_l2(o64, ref):.2e}")
+    assert float(ratio.max()) <= 1.0
 
 
 def test_attention_fused_qk_buffer_and_online_rescale(hip, dev):

@@ -3,10 +3,12 @@ weights, same seeded inputs), plus the API-shape tests that mirror the reference
 (/root/reference/tests/test_pipeline.py:41-81: they assert only that the output exists).
 
 Stated tolerances (bf16 HIP path vs fp32 oracle; SURVEY.md 8c ladder - "parity unpinned" for these
-networks because diffusers cannot be run to pin the oracle):
-  * one UNet forward            PSNR >= 40 dB on eps (peak = max |eps_oracle|)
-  * VAE decode                  PSNR >= 35 dB on the [0,1] image, uint8 max-abs reported
-  * full frame, few steps       PSNR >= 30 dB on the uint8 image
+networks because diffusers cannot be run to pin the oracle).  Every gate sits 3 dB under the value measured on
+MI355X (profiles/round2_parity_report.txt), so a regression that doubles the error fails:
+  * one UNet forward            PSNR >= 46 dB on eps (peak = max |eps_oracle|; measured 48.5 - 49.7)
+  * VAE decode                  PSNR >= 45.5 dB on the [0,1] image (measured 48.6 / 49.8), uint8 max-abs reported
+  * full frame, 2 - 10 steps    PSNR >= 39 dB on the image (measured 42.0 - 43.4)
+  * BASELINE config 1, 50 steps see test_baseline_config1_50_steps_vs_golden
 """
 import json
 from pathlib import Path
@@ -57,7 +59,7 @@ def test_tiny_unet_forward(hip, dev, tiled):
         ref = oracle(x, torch.tensor(501), ctx)
     p = psnr(got, ref)
     report(f"tiny unet (tiled={tiled}) eps PSNR {p:.1f} dB, rel-L2 {rel_l2(got, ref):.2e}")
-    assert p >= 40.0
+    assert p >= (45.5 if tiled else 46.5)
 
 
 def test_sd14_unet_forward_small_latent(hip, dev):
@@ -72,7 +74,7 @@ def test_sd14_unet_forward_small_latent(hip, dev):
         ref = oracle(x, torch.tensor(981), ctx)
     p = psnr(got, ref)
     report(f"SD-1.4 unet eps PSNR {p:.1f} dB, rel-L2 {rel_l2(got, ref):.2e}, |eps|max {float(ref.abs().max()):.3f}")
-    assert p >= 40.0
+    assert p >= 46.5
 
 
 def test_sd21_unet_forward_small_latent(hip, dev):
@@ -86,7 +88,7 @@ def test_sd21_unet_forward_small_latent(hip, dev):
         ref = oracle(x, torch.tensor(981), ctx)
     p = psnr(got, ref)
     report(f"SD-2.1 unet eps PSNR {p:.1f} dB")
-    assert p >= 40.0
+    assert p >= 46.5
 
 
 @pytest.mark.parametrize("arch", ["tiny", "sd"])
@@ -106,7 +108,7 @@ def test_vae_decode(hip, dev, arch):
     report(f"{arch} vae image PSNR {p:.1f} dB, uint8 max-abs {d8.max()}, mean-abs {d8.mean():.3f}, "
           f"dynamic range [{ref.min():.2f},{ref.max():.2f}] std {ref.std():.3f}")
     assert got.shape == ref.shape == (2, 64, 64, 3)
-    assert p >= 35.0
+    assert p >= (45.5 if arch == "tiny" else 46.5) and d8.max() <= 10
     assert np.array_equal(u8.cpu().numpy(), (got * 255).round().astype("uint8"))
 
 
@@ -145,14 +147,14 @@ def test_pipeline_call_matches_oracle(hip, dev):
         p = psnr(torch.from_numpy(out), torch.from_numpy(ref), peak=1.0)
         d8 = np.abs((out * 255).round().astype(int) - ref8.astype(int))
         report(f"pipeline (graphs={graphs}) frame PSNR {p:.1f} dB, uint8 max-abs {d8.max()} mean-abs {d8.mean():.3f}")
-        assert out.shape == (2, 64, 64, 3) and p >= 30.0
+        assert out.shape == (2, 64, 64, 3) and p >= 40.0
     assert np.array_equal(outs[True], outs[False]), "hipGraph replay must equal eager launches bit-for-bit"
     # latents after the loop (before the VAE), which is where chained-step error shows
     lat_ref = denoise_and_decode(o_unet, o_vae, OracleDDIM(), emb, uncond, lat, 10, 7.5, return_latents=True)
     lat_got = pipe(latents=lat, text_embeddings=emb, height=64, width=64, num_inference_steps=10, guidance_scale=7.5,
                    return_latents=True).cpu()
     report(f"latents after 10 steps: PSNR {psnr(lat_got, lat_ref):.1f} dB")
-    assert psnr(lat_got, lat_ref) >= 35.0
+    assert psnr(lat_got, lat_ref) >= 40.5
     # PIL output type and no-CFG path
     ims = pipe(latents=lat[:1], text_embeddings=emb[:1], height=64, width=64, num_inference_steps=3, guidance_scale=1.0).images
     assert len(ims) == 1 and ims[0].size == (64, 64)
@@ -262,7 +264,7 @@ def test_sd14_full_size_two_steps(hip, dev):
     p = psnr(torch.from_numpy(out), torch.from_numpy(ref), peak=1.0)
     d8 = np.abs((out * 255).round().astype(int) - numpy_to_uint8(ref).astype(int))
     report(f"SD-1.4 512x512, 2 steps, CFG: frame PSNR {p:.1f} dB, uint8 max-abs {d8.max()} mean-abs {d8.mean():.3f}")
-    assert out.shape == (1, 512, 512, 3) and p >= 30.0
+    assert out.shape == (1, 512, 512, 3) and p >= 39.0
 
 
 def test_baseline_config1_50_steps_vs_golden(hip, dev, tmp_path):
@@ -342,7 +344,7 @@ def test_pipeline_variants(hip, dev):
                                  variance_noise=list(noise))
         p = psnr(torch.from_numpy(out), torch.from_numpy(ref), peak=1.0)
         report(f"tiny pipeline {ptype} eta=0.5 negative prompt: frame PSNR {p:.1f} dB")
-        assert p >= 30.0
+        assert p >= 39.0
     ims = pipe(prompt=["a cat", "a dog"], height=64, width=64, num_inference_steps=2, num_images_per_prompt=2,
                generator=torch.Generator().manual_seed(0)).images
     assert len(ims) == 4
@@ -421,7 +423,7 @@ def _esrgan_pair(dev, num_block, probe, seed=0):
 
 @pytest.mark.parametrize("num_block,n,H,W", [(2, 2, 24, 40), (23, 1, 64, 64)])
 def test_esrgan_matches_oracle(hip, dev, num_block, n, H, W):
-    """Stated tolerance: PSNR >= 35 dB on the clamped [0,1] output (bf16 storage through up to 345 convs vs fp32),
+    """Stated tolerance: PSNR >= 57 dB (measured 60.0 / 66.4) on the clamped [0,1] output (bf16 storage through up to 345 convs vs fp32),
     uint8 frames within a few grey levels.  **parity unpinned** (oracle/esrgan.py)."""
     from oracle.esrgan import enhance_rgb_u8
     g = torch.Generator().manual_seed(5)
@@ -439,7 +441,7 @@ def test_esrgan_matches_oracle(hip, dev, num_block, n, H, W):
     report(f"esrgan blocks={num_block} {n}x{H}x{W}: PSNR {p:.1f} dB, uint8 max|d| {int(d.max())}, mean|d| {d.mean():.3f}, "
            f"unclamped fraction {frac_mid:.2f}")
     assert frac_mid > 0.9, "synthetic output saturates: the comparison would be vacuous"
-    assert p >= 35.0
+    assert p >= 57.0
     assert d.mean() < 1.5
     # chunked execution (several frames per call, one frame per chunk) is bit-identical
     engine.max_chunk_pixels = H * W
@@ -483,7 +485,7 @@ def _clip_golden(act):
 
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
 def test_clip_text_engine_matches_transformers_golden(hip, dev, act):
-    """Stated tolerance: PSNR >= 40 dB against last_hidden_state of transformers.CLIPTextModel (tests/golden/clip_*.npz,
+    """Stated tolerance: PSNR >= 47.5 dB (measured 50.7 / 51.4) against last_hidden_state of transformers.CLIPTextModel (tests/golden/clip_*.npz,
     generated by tests/golden/make_golden_clip.py; weights are bf16-exact so both sides share them bit for bit)."""
     from stable_diffusion_videos_amd.config import TextConfig
     from stable_diffusion_videos_amd.text import CLIPTextEngine
@@ -502,7 +504,7 @@ def test_clip_text_engine_matches_transformers_golden(hip, dev, act):
     p = psnr(out.cpu(), ref)
     report(f"clip text engine ({act}, {nl} layers) vs transformers {str(z['transformers_version'])}: PSNR {p:.1f} dB, "
            f"rel-L2 {rel_l2(out.cpu(), ref):.2e}")
-    assert p >= 40.0
+    assert p >= 47.5
     # batch independence and determinism: one row alone reproduces its slice bit for bit
     assert torch.equal(eng(ids[1:2])[0], out[1:2])
     with pytest.raises(IndexError):
@@ -525,7 +527,7 @@ def test_clip_text_engine_full_size_vs_oracle(hip, dev):
     ref = clip_text_forward(sd, ids, 12, "quick_gelu")
     p = psnr(out, ref)
     report(f"clip text engine sd14 size vs oracle: PSNR {p:.1f} dB")
-    assert p >= 38.0
+    assert p >= 52.0
 
 
 def test_generate_images_on_the_hip_path(hip, dev, tmp_path):

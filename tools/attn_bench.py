@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Time the UNet's self-attention shapes (HIP events).  usage: attn_bench.py [nimg]"""
+"""Time the UNet's self-attention shapes (HIP events).  usage: attn_bench.py [nimg] [qscale ...]
+qscale multiplies Q: 1 = the N(0,1) logits of random-init weights (the O-rescale branch practically never fires), 4-6 = the
+logit spread of a trained model's self-attention (it fires in most key tiles)."""
 import sys
 from pathlib import Path
 import torch
@@ -7,10 +9,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stable_diffusion_videos_amd import hip  # noqa: E402
 
 nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+qscales = [float(a) for a in sys.argv[2:]] or [1.0]
 dev = torch.device("cuda")
-for dh, L, heads in ((40, 4096, 8), (80, 1024, 8), (160, 256, 8)):
+for qs in qscales:
+  for dh, L, heads in ((40, 4096, 8), (80, 1024, 8), (160, 256, 8)):
     C = dh * heads
-    qk = torch.randn((nimg * L, 2 * C), device=dev).to(torch.bfloat16)
+    qk = torch.randn((nimg * L, 2 * C), device=dev)
+    qk[:, :C] *= qs
+    qk = qk.to(torch.bfloat16)
     vt = torch.randn((nimg, C, L), device=dev).to(torch.bfloat16)
     o = torch.empty((nimg * L, C), dtype=torch.bfloat16, device=dev)
     fn = lambda: hip.attention(qk, qk, vt, o, B=nimg, H=heads, Lq=L, Lk=L, dh=dh, ldq=2 * C, ldk=2 * C, ldv=L, ldo=C,
@@ -22,4 +28,4 @@ for dh, L, heads in ((40, 4096, 8), (80, 1024, 8), (160, 256, 8)):
         fn()
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
-    print(f"dh={dh} L={L} nimg={nimg}: {ms:.3f} ms  {4.0 * nimg * heads * L * L * dh / ms / 1e9:.0f} TFLOP/s algorithmic")
+    print(f"qscale={qs} dh={dh} L={L} nimg={nimg}: {ms:.3f} ms  {4.0 * nimg * heads * L * L * dh / ms / 1e9:.0f} TFLOP/s algorithmic")
