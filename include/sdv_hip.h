@@ -82,6 +82,8 @@ typedef struct sdv_gemm_args {
     int32_t tile;    /* 12 = 256x320, 13 = 256x256 as a ring of four 32-wide K tiles (counted vmcnt); 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 256x32, 11 = 256x64 (4 waves) */
     float alpha;
     uint32_t div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;   /* filled in by sdv_gemm_bf16 (mode 4 row mapping); callers leave 0 */
+    int32_t alpha_cols;   /* > 0: alpha multiplies only output columns [0, alpha_cols) (the Q half of a fused [Q | K] projection:
+                             q * softmax_scale * log2(e) is rounded to bf16 ONCE, here, not a second time inside the attention) */
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
@@ -96,10 +98,15 @@ int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
  *   O  [B][Lq][ldo]
  * dh in {40, 64, 80, 160}.  causal != 0 masks key > query (CLIPTextModel's causal mask, reached from
  * text_encoder(ids)[0], stable_diffusion_pipeline.py:819; needs Lq == Lk).
+ * q_prescaled != 0: Q already holds q * scale * log2(e) (its projection GEMM applied it before its single bf16 rounding,
+ * sdv_gemm_args.alpha / alpha_cols) and `scale` is ignored.  With q_prescaled == 0 the 40 / 80-wide-head kernels pre-multiply Q
+ * themselves and round it to bf16 a second time: measured 4.6e-3 instead of 1.9e-3 rel-L2 once the logits are as peaked as a
+ * trained model's (tests/test_kernels_gpu.py::test_attention_elementwise_bound).
  * ------------------------------------------------------------------------------------------ */
 int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O,
                        int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dh,
-                       int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, int32_t causal, void* stream);
+                       int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, int32_t causal,
+                       int32_t q_prescaled, void* stream);
 
 /* row softmax in place over bf16 rows (VAE mid-block attention, 1 head x 512 channels) */
 int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, int32_t ld, void* stream);

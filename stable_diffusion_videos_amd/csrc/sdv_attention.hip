@@ -512,7 +512,8 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
     static const bool prio = !(getenv("SDV_ATTN_PRIO") && atoi(getenv("SDV_ATTN_PRIO")) == 0);   // default on (+1..3 %)
     static const bool lean_env = !(getenv("SDV_ATTN_LEAN") && atoi(getenv("SDV_ATTN_LEAN")) == 0);
     const bool lean = lean_env && (DH % 32 != 0);   // dh = 64 / 160 have no padding rows or columns to exploit
-    const float sl = scale * 1.4426950408889634f;
+    const float sl = scale * 1.4426950408889634f;   // (the caller passes 1 / log2(e) for a pre-scaled Q: sl == 1, the
+                                                    //  kernels' own Q scaling then reproduces the bf16 values bit for bit)
 #define SDV_ATTN_LAUNCH(P, L, D) \
     hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, \
                        causal, B * H)
@@ -603,7 +604,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(uint16_t* __restrict_
 
 extern "C" int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O, int32_t B,
                                   int32_t H, int32_t Lq, int32_t Lk, int32_t dh, int32_t ldq, int32_t ldk, int32_t ldv,
-                                  int32_t ldo, float scale, int32_t causal, void* stream) {
+                                  int32_t ldo, float scale, int32_t causal, int32_t q_prescaled, void* stream) {
+    if (q_prescaled) scale = 0.6931471805599453f;   // * log2(e) == 1
     SDV_REQUIRE(Q && K && Vt && O, "sdv_attention_bf16: null pointer");
     SDV_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sdv_attention_bf16: bad shape");
     SDV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sdv_attention_bf16: unaligned leading dims");

@@ -424,6 +424,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 
     // ---- epilogue ------------------------------------------------------------------------------
     const float alpha = p.alpha;
+    const int acols = p.alpha_cols > 0 ? p.alpha_cols : 0x7fffffff;
     const float* bias = p.bias;
     if (bias && p.step_ptr) bias += (long long)(*p.step_ptr) * p.bias_step_stride;
     uint16_t* __restrict__ C = p.C + bz * p.sC;
@@ -516,10 +517,11 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                                 bv.w += t4.w;
                             }
                             float4 o;
-                            o.x = acc[nt][mt][4 * g4 + 0] * alpha + bv.x;
-                            o.y = acc[nt][mt][4 * g4 + 1] * alpha + bv.y;
-                            o.z = acc[nt][mt][4 * g4 + 2] * alpha + bv.z;
-                            o.w = acc[nt][mt][4 * g4 + 3] * alpha + bv.w;
+                            const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
+                            o.x = acc[nt][mt][4 * g4 + 0] * al + bv.x;
+                            o.y = acc[nt][mt][4 * g4 + 1] * al + bv.y;
+                            o.z = acc[nt][mt][4 * g4 + 2] * al + bv.z;
+                            o.w = acc[nt][mt][4 * g4 + 3] * al + bv.w;
                             const int chunk = j * 8 + 2 * g4 + lhi;
                             *(float4*)(stg + l31_p * 64 + ((chunk ^ (l31_p & 7)) << 2)) = o;
                         }
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[nt][mt][4 * g4 + e] * alpha + bm_;
+                    v[e] = acc[nt][mt][4 * g4 + e] * (nb < acols ? alpha : 1.f) + bm_;
                     if (bias && p.bias_mode == 1 && nb + e < p.N) v[e] += bias[nb + e];
                 }
                 if (vec_ok && nb + 3 < p.N) {
@@ -762,6 +764,8 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     }
     if (a.bias_mode == 0 && a.bias) a.bias_mode = 1;
     if (a.alpha == 0.f) a.alpha = 1.f;
+    SDV_REQUIRE(a.alpha_cols >= 0 && a.alpha_cols % 8 == 0 && (a.alpha_cols == 0 || a.epi != 1),
+                "sdv_gemm_bf16: alpha_cols=%d must be a multiple of 8 (and is not available with GEGLU)", a.alpha_cols);
     hipStream_t s = (hipStream_t)stream;
     int tile = a.tile;
     const long long nb = a.batch > 0 ? a.batch : 1;

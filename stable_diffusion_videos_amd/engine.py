@@ -132,29 +132,30 @@ class _Transformer:
         h = hip.linear(h, self.w_in, self.b_in)
         # --- self attention ---
         n1 = hip.layernorm(h, *self.ln[0])
-        qk = hip.linear(n1, self.wqk1)                                    # [Mb, 2C] = [Q | K]
+        qs = hip.q_prescale(dh)       # softmax scale * log2(e), applied by the Q projections before their single rounding
+        qk = hip.linear(n1, self.wqk1, alpha=qs, alpha_cols=C)            # [Mb, 2C] = [Q * qs | K]
         ldv = _round_up(HW, 64)
         hip.gemm(self.wv1, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C,
                  sC=C * ldv)                                              # V^T [nb][C][ldv]
         o = torch.empty((Mb, C), dtype=BF16, device=x.device)
         hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
-                      scale=scale, k_off=C)
+                      scale=scale, k_off=C, q_prescaled=True)
         h = hip.linear(o, self.wo1, self.bo1, residual=h)
         # --- cross attention on the text context ---
         n2 = hip.layernorm(h, *self.ln[1])
-        q = hip.linear(n2, self.wq2)
+        q = hip.linear(n2, self.wq2, alpha=qs)
         o2 = torch.empty((M, C), dtype=BF16, device=x.device)
         ctx_k, ctx_vt, Lc = self.ctx[nimg]
         if not shared_prefix:
             hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
-                          ldo=C, scale=scale)
+                          ldo=C, scale=scale, q_prescaled=True)
             h = hip.linear(o2, self.wo2, self.bo2, residual=h)
         else:
             # same queries against the unconditional and the conditional context; the residual stream h is still
             # shared, so the output projection reads it with batch stride 0 and writes both halves
             for half in range(2):
                 hip.attention(q, ctx_k[half * nb * Lc:], ctx_vt[half * nb:], o2[half * Mb:], B=nb, H=heads, Lq=HW, Lk=Lc,
-                              dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2], ldo=C, scale=scale)
+                              dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2], ldo=C, scale=scale, q_prescaled=True)
             h2 = torch.empty((M, C), dtype=BF16, device=x.device)
             hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
                      sX=Mb * C, sW=0, sC=Mb * C, sR=0)

@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("epi", C.c_int32), ("bias_mode", C.c_int32), ("bias_step_stride", C.c_int32),
         ("batch", C.c_int32), ("tile", C.c_int32), ("alpha", C.c_float),
         ("div_hw_mul", C.c_uint32), ("div_hw_shr", C.c_uint32), ("div_w_mul", C.c_uint32), ("div_w_shr", C.c_uint32),
+        ("alpha_cols", C.c_int32),
     ]
 
 
@@ -45,7 +46,7 @@ _SIGNATURES = {
     "sdv_last_error": (C.c_char_p, []),
     "sdv_abi_version": (C.c_int, []),
     "sdv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
-    "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_void_p]),
+    "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
@@ -158,7 +159,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          epi: int = 0, mode: int = 0, Hin: int = 0, Win: int = 0, Hout: int = 0, Wout: int = 0,
          circular: bool = False, batch: int = 1, sX: int = 0, sW: int = 0, sC: int = 0, sR: int = 0,
          step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
-         x_off: int = 0, w_off: int = 0, out_off: int = 0):
+         x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0):
     """Raw wrapper of ``sdv_gemm_bf16`` (element offsets x_off / w_off / out_off select sub-matrices)."""
     lib = load()
     a = GemmArgs()
@@ -175,7 +176,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     a.ldx, a.ldx2, a.C1, a.ldw, a.ldc, a.ldr = ldx, ldx2, C1, ldw, ldc, ldr
     a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, Hin, Win, Hout, Wout, int(circular)
     a.epi, a.bias_mode, a.bias_step_stride = epi, (bias_mode if bias is not None else 0), bias_step_stride
-    a.batch, a.tile, a.alpha = batch, tile, alpha
+    a.batch, a.tile, a.alpha, a.alpha_cols = batch, tile, alpha, alpha_cols
     taps = 1 if mode == 0 else 9
     # algorithmic work: the phase form (mode 4) is a nearest-2x upsample + conv3x3 on 4*M output pixels (9 taps each);
     # it EXECUTES 4 taps per output pixel
@@ -186,7 +187,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, residual=None, out=None,
-           epi: int = 0, x2: Optional[torch.Tensor] = None, alpha: float = 1.0, tile: int = 0) -> torch.Tensor:
+           epi: int = 0, x2: Optional[torch.Tensor] = None, alpha: float = 1.0, tile: int = 0, alpha_cols: int = 0) -> torch.Tensor:
     """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias) (+ residual); x2 = optional second K-source (concat)."""
     M, K1 = x.shape
     K2 = x2.shape[1] if x2 is not None else 0
@@ -200,7 +201,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         out = torch.empty((M, n_out), dtype=BF16, device=x.device)
     gemm(x, w, out, M=M, N=N, K=K, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
          residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2, C1=K1 if x2 is not None else 0,
-         ldx2=x2.stride(0) if x2 is not None else 0, alpha=alpha, epi=epi, tile=tile)
+         ldx2=x2.stride(0) if x2 is not None else 0, alpha=alpha, epi=epi, tile=tile, alpha_cols=alpha_cols)
     return out
 
 
@@ -255,13 +256,20 @@ def upconv3x3_phase(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tens
 # ------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Lq: int,
               Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0,
-              causal: bool = False):
+              causal: bool = False, q_prescaled: bool = False):
+    """softmax(Q K^T scale) V.  ``q_prescaled``: Q already holds q * scale * log2(e) (``LOG2E_SCALE(dh)`` applied as the
+    ``alpha`` of its projection GEMM, one bf16 rounding in total) and ``scale`` is ignored."""
     lib = load()
     qp, kp, vp, op = _ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off, _ptr(vt, BF16, "Vt"), _ptr(out, BF16, "O")
     _launch("attention", dict(B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, flops=4.0 * B * H * Lq * Lk * dh),
             lambda: _check(lib.sdv_attention_bf16(qp, kp, vp, op, B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, scale, int(causal),
-                                                  _stream()),
+                                                  int(q_prescaled), _stream()),
                            "sdv_attention_bf16"))
+
+
+def q_prescale(dh: int) -> float:
+    """softmax scale * log2(e): what the attention kernels want Q multiplied by (they exponentiate in base 2)."""
+    return dh ** -0.5 * 1.4426950408889634
 
 
 def softmax_rows_(s: torch.Tensor, rows: int, cols: int, ld: int):

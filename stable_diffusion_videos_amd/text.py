@@ -89,6 +89,7 @@ class CLIPTextEngine:
             w = {"tok": sd["embeddings.token_embedding.weight"].to(device, torch.float32).contiguous(),
                  "pos": sd["embeddings.position_embedding.weight"].to(device, torch.float32).contiguous(),
                  "fin": (vec(sd["final_layer_norm.weight"], device), vec(sd["final_layer_norm.bias"], device)), "layers": []}
+            qs = hip.q_prescale(c.hidden_size // c.num_attention_heads)
             for i in range(c.num_hidden_layers):
                 p = f"encoder.layers.{i}."
                 a = p + "self_attn."
@@ -96,7 +97,8 @@ class CLIPTextEngine:
                     ln1=(vec(sd[p + "layer_norm1.weight"], device), vec(sd[p + "layer_norm1.bias"], device)),
                     ln2=(vec(sd[p + "layer_norm2.weight"], device), vec(sd[p + "layer_norm2.bias"], device)),
                     wqk=lin_w(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"]], 0), device),
-                    bqk=vec(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"]], 0), device),
+                    # the Q half of the bias carries the softmax scale * log2(e) that the projection's alpha puts on Q
+                    bqk=vec(torch.cat([sd[a + "q_proj.bias"].float() * qs, sd[a + "k_proj.bias"].float()], 0), device),
                     wv=lin_w(sd[a + "v_proj.weight"], device), bv=vec(sd[a + "v_proj.bias"], device),
                     wo=lin_w(sd[a + "out_proj.weight"], device), bo=vec(sd[a + "out_proj.bias"], device),
                     w1=lin_w(sd[p + "mlp.fc1.weight"], device), b1=vec(sd[p + "mlp.fc1.bias"], device),
@@ -131,11 +133,11 @@ class CLIPTextEngine:
         o = torch.empty_like(x)
         for lw in w["layers"]:
             h = hip.layernorm(x, *lw["ln1"], eps=1e-5)
-            qk = hip.linear(h, lw["wqk"], lw["bqk"])                                           # [M, 2D] = [Q | K]
+            qk = hip.linear(h, lw["wqk"], lw["bqk"], alpha=hip.q_prescale(dh), alpha_cols=D)   # [M, 2D] = [Q * qs | K]
             hip.gemm(lw["wv"], h, vt, M=D, N=L, K=D, ldx=D, ldw=D, ldc=ldv, bias=lw["bv"], bias_mode=2, batch=B,
                      sX=0, sW=L * D, sC=D * ldv)                                               # V^T (+ bias per channel)
             hip.attention(qk, qk, vt, o, B=B, H=H, Lq=L, Lk=L, dh=dh, ldq=2 * D, ldk=2 * D, ldv=ldv, ldo=D,
-                          scale=dh ** -0.5, k_off=D, causal=True)
+                          scale=dh ** -0.5, k_off=D, causal=True, q_prescaled=True)
             x = hip.linear(o, lw["wo"], lw["bo"], residual=x)
             h = hip.layernorm(x, *lw["ln2"], eps=1e-5)
             f = hip.linear(h, lw["w1"], lw["b1"], epi=epi)

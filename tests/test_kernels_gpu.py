@@ -80,6 +80,11 @@ def test_gemm_epilogues(hip, dev, tile):
     hip.gemm(x.to(BF16), w.to(BF16), out, M=M, N=N, K=K, ldx=K, ldw=K, ldc=N, bias=bias_m, bias_mode=2, alpha=0.25,
              tile=tile)
     assert rel_l2(out.float(), 0.25 * (x @ w.T) + bias_m[:, None]) < MFMA_TOL
+    # alpha on the leading columns only (fused [Q | K] projection: Q pre-scaled for the attention kernel)
+    out = hip.linear(x.to(BF16), w.to(BF16), bias_n, alpha=0.37, alpha_cols=96, tile=tile)
+    ref = x @ w.T
+    ref[:, :96] *= 0.37
+    assert rel_l2(out.float(), ref + bias_n) < MFMA_TOL
     # SiLU epilogue
     out = hip.linear(x.to(BF16), w.to(BF16), bias_n, epi=2, tile=tile)
     assert rel_l2(out.float(), F.silu(x @ w.T + bias_n)) < MFMA_TOL
@@ -370,39 +375,48 @@ def _attn_ref64(q, k, v, heads, scale):
     return out, mag
 
 
-@pytest.mark.parametrize("dh,Lq,Lk,qscale", [(40, 4096, 4096, 1.0), (40, 4096, 4096, 5.0), (40, 4096, 77, 1.0), (80, 1024, 1024, 1.0),
-                                             (80, 1024, 1024, 5.0), (160, 256, 256, 1.0), (64, 1024, 1024, 5.0)])
-def test_attention_elementwise_bound(hip, dev, dh, Lq, Lk, qscale):
+@pytest.mark.parametrize("dh,Lq,Lk,qscale,prescaled", [(40, 4096, 4096, 1.0, True), (40, 4096, 4096, 5.0, True), (40, 4096, 77, 1.0, True),
+                                                       (80, 1024, 1024, 1.0, True), (80, 1024, 1024, 5.0, True), (160, 256, 256, 1.0, True),
+                                                       (64, 1024, 1024, 5.0, True), (40, 4096, 4096, 1.0, False), (64, 1024, 1024, 5.0, False)])
+def test_attention_elementwise_bound(hip, dev, dh, Lq, Lk, qscale, prescaled):
     """Element-by-element bound against a float64 softmax(QK^T)V of the same bf16 inputs, on the UNet's real attention
-    shapes (64 x 64 level: dh 40, 4096 tokens; cross-attention: 77 keys).  The kernel rounds P to bf16 before the PV MFMA
-    (and, for the 40 / 80-wide heads, the pre-scaled Q), so the bound is half a bf16 ulp of the output plus
-    2^-6 * sum_k p_k |v_k| (measured worst case 0.3 - 0.5 of that on MI355X) - a dropped or doubled key tile moves an
-    output by ~1/64 of sum p |v| per tile at these sizes and fails it, which the 6e-3 rel-L2 gate cannot see.  The
-    channel pattern of V makes every key tile visible: channel d of V is 1 on the keys of tile d (mod dh) and random noise
-    elsewhere.  qscale = 5 multiplies Q so that the logits have the spread of a TRAINED model's self-attention (std ~5
-    instead of ~1): the running max then jumps by more than the deferral threshold in most tiles and the O-rescale branch
-    runs all the time instead of never."""
+    shapes (64 x 64 level: dh 40, 4096 tokens; cross-attention: 77 keys).  The kernel rounds P to bf16 before the PV MFMA,
+    so the bound is half a bf16 ulp of the output plus 2^-6 * sum_k p_k |v_k| (measured worst case 0.1 - 0.4 of that on
+    MI355X) - a dropped or doubled key tile moves an output by ~1/64 of sum p |v| per tile at these sizes and fails it,
+    which the 6e-3 rel-L2 gate cannot see.  The channel pattern of V makes every key tile visible: channel d of V is 1 on the
+    keys of tile d (mod dh) and random noise elsewhere.  qscale = 5 multiplies Q so that the logits have the spread of a
+    TRAINED model's self-attention (std ~5 instead of ~1): the running max then jumps by more than the deferral threshold
+    in most tiles and the O-rescale branch runs all the time instead of never.
+    ``prescaled`` is how the engines call the kernel: Q arrives as q * scale * log2(e), rounded to bf16 once by its
+    projection GEMM.  (With raw Q the 40 / 80-wide-head kernels pre-multiply and round a second time: at qscale 5 that
+    measured 1.9 x this bound / 4.6e-3 rel-L2 instead of 0.34 x / 1.9e-3 - why the product path pre-scales in the GEMM.)"""
     B, heads = 1, 8
     Cc = heads * dh
-    q, k = rnd((B, Lq, Cc), dev, 70, qscale), rnd((B, Lk, Cc), dev, 71)
+    scale = dh ** -0.5
+    if prescaled:
+        q = rnd((B, Lq, Cc), dev, 70, qscale * hip.q_prescale(dh))       # what the projection GEMM hands over
+        q_true = q.double().cpu() / hip.q_prescale(dh)                   # the q this bf16 value stands for
+    else:
+        q = rnd((B, Lq, Cc), dev, 70, qscale)
+        q_true = q.double().cpu()
+    k = rnd((B, Lk, Cc), dev, 71)
     v = rnd((B, Lk, Cc), dev, 72, 0.25)
     tile_of_key = (torch.arange(Lk, device=dev) // 64) % dh
     for h in range(heads):
         v[0, torch.arange(Lk, device=dev), h * dh + tile_of_key] = 1.0
-    scale = dh ** -0.5
-    ref, mag = _attn_ref64(q.double().cpu(), k.double().cpu(), v.double().cpu(), heads, scale)
+    ref, mag = _attn_ref64(q_true, k.double().cpu(), v.double().cpu(), heads, scale)
     ldv = (Lk + 63) // 64 * 64
     vt = torch.zeros((B, Cc, ldv), dtype=BF16, device=dev)
     vt[:, :, :Lk] = v.transpose(1, 2).to(BF16)
     out = torch.empty((B * Lq, Cc), dtype=BF16, device=dev)
     hip.attention(q.reshape(-1, Cc).to(BF16), k.reshape(-1, Cc).to(BF16), vt, out, B=B, H=heads, Lq=Lq, Lk=Lk, dh=dh, ldq=Cc,
-                  ldk=Cc, ldv=ldv, ldo=Cc, scale=scale)
+                  ldk=Cc, ldv=ldv, ldo=Cc, scale=scale, q_prescaled=prescaled)
     torch.cuda.synchronize()
     o64 = out.double().cpu().view(B, Lq, Cc)
     ratio = _half_ulp_ratio(o64, ref, mag, acc_eps=2.0 ** -6)
     from conftest import report
-    report(f"attention dh={dh} Lq={Lq} Lk={Lk} qscale={qscale}: worst element at {float(ratio.max()):.3f} of (half ulp + 2^-6 sum p|v|), "
-           f"rel-L2 {rel_l2(o64, ref):.2e}")
+    report(f"attention dh={dh} Lq={Lq} Lk={Lk} qscale={qscale} prescaled={prescaled}: worst element at {float(ratio.max()):.3f} of "
+           f"(half ulp + 2^-6 sum p|v|), rel-L2 {rel_l2(o64, ref):.2e}")
     assert float(ratio.max()) <= 1.0
 
 
