@@ -104,17 +104,21 @@ class _Transformer:
         self.dh = self.C // heads
         self.groups = groups
         # per batch size: (K [N*Lc, C], V^T [N, C, ldv] zero padded, Lc) - persistent so captured graphs stay valid
-        self.ctx: Dict[int, tuple] = {}
+        self.ctx: Dict[int, tuple] = {}            # the (K, V^T, Lc) the next forward of a given batch size uses
+        self.ctx_by_len: Dict[tuple, tuple] = {}
 
     def prepare_context(self, ctx: torch.Tensor, nimg: int, Lc: int):
         """ctx: bf16 [nimg*Lc, D].  K = ctx Wk^T ; V^T[n] = Wv ctx[n]^T  (constant across denoise steps)."""
         C, D = self.C, ctx.shape[1]
         ldv = _round_up(Lc, 64)
-        ent = self.ctx.get(nimg)
-        if ent is None or ent[2] != Lc:
+        ent = self.ctx_by_len.get((nimg, Lc))
+        if ent is None:
+            # keyed by (nimg, Lc) and never freed: captured graphs hold raw pointers into these buffers, so a call with a
+            # different context length must not reallocate the ones an older graph still reads
             ent = (torch.empty((nimg * Lc, C), dtype=BF16, device=ctx.device),
                    torch.zeros((nimg, C, ldv), dtype=BF16, device=ctx.device), Lc)
-            self.ctx[nimg] = ent
+            self.ctx_by_len[(nimg, Lc)] = ent
+        self.ctx[nimg] = ent
         hip.linear(ctx, self.wk2, out=ent[0])
         hip.gemm(self.wv2, ctx, ent[1], M=C, N=Lc, K=D, ldx=D, ldw=D, ldc=ldv, batch=nimg, sX=0, sW=Lc * D,
                  sC=C * ldv)

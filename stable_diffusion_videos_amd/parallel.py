@@ -31,7 +31,8 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("SDV_FORCE_DEVICE") is not None:      # functional tests of the N-rank path on a 1-GPU box
         local = int(os.environ["SDV_FORCE_DEVICE"])
-    if ws > 1 and not dist.is_initialized():
+    # SDV_DIST_INIT=1 builds a process group even for ONE rank: the RCCL broadcast path then runs on a 1-GPU box
+    if (ws > 1 or os.environ.get("SDV_DIST_INIT") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -54,7 +55,16 @@ def partition_frames(frame_counts: Sequence[int], world_size: int, rank: int,
     already on disk (resume).  Blocks are contiguous in (clip, frame) order so a rank keeps its clip
     endpoints hot and works in full batches; sizes differ by at most one frame."""
     skips = list(skips) if skips is not None else [0] * len(frame_counts)
-    todo = [(i, k) for i, n in enumerate(frame_counts) for k in range(skips[i], n)]
+    return partition_frame_list([list(range(skips[i], n)) for i, n in enumerate(frame_counts)], world_size, rank)
+
+
+def partition_frame_list(todo_per_clip: Sequence[Sequence[int]], world_size: int, rank: int) -> List[Tuple[int, int, int]]:
+    """As ``partition_frames`` for an ARBITRARY set of frames per clip (``todo_per_clip[i]`` = sorted frame indices of
+    clip i that still have to be generated).  A resumed multi-rank (or hard-killed) run leaves holes, not a prefix: rank 0
+    may have died at frame 20 of its block and rank 1 at frame 70 of its own, so "continue after the last frame on disk"
+    (the reference's rule, which assumes one sequential writer) would never produce frames 21-49.  The share is returned
+    as runs of consecutive frames ``(clip, first, stop)``."""
+    todo = [(i, k) for i, frames in enumerate(todo_per_clip) for k in frames]
     total = len(todo)
     base, extra = divmod(total, world_size)
     start = rank * base + min(rank, extra)
@@ -69,6 +79,16 @@ def partition_frames(frame_counts: Sequence[int], world_size: int, rank: int,
     return out
 
 
+def broadcast_object(obj, src: int = 0):
+    """Rank ``src``'s picklable object on every rank (run name, resume decisions)."""
+    rank, ws = world()
+    if ws == 1:
+        return obj
+    box = [obj if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def broadcast_state_dict(sd: Dict[str, torch.Tensor], shapes: Dict[str, tuple], device, src: int = 0
                          ) -> Dict[str, torch.Tensor]:
     """One-time weight distribution: rank ``src`` holds ``sd``; everyone returns an identical dict.
@@ -77,8 +97,9 @@ def broadcast_state_dict(sd: Dict[str, torch.Tensor], shapes: Dict[str, tuple], 
     two large broadcasts (~1.7 GB + a few MB for the UNet) instead of ~700 small ones, which is what a
     point-to-point xGMI fabric wants.  bf16 is what the kernels consume, so nothing is lost."""
     rank, ws = world()
-    if ws == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return sd
+    # (a 1-rank process group still takes the broadcast path: that is how the RCCL code is exercised on a 1-GPU box)
     mats = [k for k, s in shapes.items() if len(s) > 1]
     vecs = [k for k, s in shapes.items() if len(s) == 1]
     n_m = sum(int(torch.tensor(shapes[k]).prod()) for k in mats)
@@ -100,20 +121,19 @@ def broadcast_state_dict(sd: Dict[str, torch.Tensor], shapes: Dict[str, tuple], 
             o += n
     dist.broadcast(buf_m, src=src)
     dist.broadcast(buf_v, src=src)
-    if use_gpu:
-        # hand the engines host tensors, exactly as in the single-GPU path (the per-layer re-layout then uploads bf16):
-        # one 1.7 GB D2H copy per rank at start-up buys ONE weight code path for 1 and N GPUs
-        buf_m, buf_v = buf_m.cpu(), buf_v.cpu()
+    # RCCL: the buffers stay in HBM and the engines re-lay-out straight from these device views (bf16 matrices, fp32
+    # vectors) - no D2H copy, no fp32 widening on the host cores that all ranks of a node share.
     out: Dict[str, torch.Tensor] = {}
     o = 0
     for k in mats:
         n = int(torch.tensor(shapes[k]).prod())
-        out[k] = buf_m[o:o + n].view(*shapes[k]).float()
+        v = buf_m[o:o + n].view(*shapes[k])
+        out[k] = v if use_gpu else v.float()
         o += n
     o = 0
     for k in vecs:
         n = int(shapes[k][0])
-        out[k] = buf_v[o:o + n].clone()
+        out[k] = buf_v[o:o + n] if use_gpu else buf_v[o:o + n].clone()
         o += n
     return out
 

@@ -90,6 +90,7 @@ class StableDiffusionWalkPipeline:
         self.cfg_shared_prefix = os.environ.get("SDV_NO_CFG_SHARED", "0") != "1"   # see UNetEngine.forward
         self._device = torch.device("cpu")
         self._graphs: Dict[tuple, dict] = {}
+        self.max_cached_graphs = 4         # LRU bound on captured denoise-step graphs (each has its own memory pool)
         self._uncond_cache: Dict[str, torch.Tensor] = {}
         self._sched_cache: Dict[tuple, tuple] = {}
         self._writer: Optional[FrameWriter] = None
@@ -115,9 +116,20 @@ class StableDiffusionWalkPipeline:
             model_dir = Path(name)
         elif os.environ.get("SDV_MODEL_DIR") and Path(os.environ["SDV_MODEL_DIR"]).is_dir():
             model_dir = Path(os.environ["SDV_MODEL_DIR"])
+            logger.warning("from_pretrained(%r): not a local directory - loading $SDV_MODEL_DIR=%s instead", name, model_dir)
+        synthetic = bool(kwargs.pop("synthetic", False)) or arch is not None or name.lower() == "tiny"
+        if model_dir is None and not synthetic:
+            # a hub id or a mistyped path must not silently turn into noise frames from random weights
+            raise FileNotFoundError(
+                f"from_pretrained({name!r}): no such local diffusers-layout directory (there is no network here, hub ids "
+                "cannot be downloaded).  Point it at a model directory / set $SDV_MODEL_DIR, or ask explicitly for the "
+                "architecture with seeded SYNTHETIC weights: arch='sd14' | 'sd21' | 'tiny' (or synthetic=True).")
         if arch is None:
             low = name.lower()
             arch = "tiny" if "tiny" in low else ("sd21" if ("stable-diffusion-2" in low or "sd21" in low) else "sd14")
+        if model_dir is None:
+            logger.warning("from_pretrained(%r): building the %s architecture with seeded SYNTHETIC weights and the hash "
+                           "tokenizer (no checkpoint on disk) - outputs are for benchmarking / parity only", name, arch)
         if torch_dtype not in (None, torch.bfloat16, torch.float16, torch.float32):
             raise ValueError(f"unsupported torch_dtype {torch_dtype}")
         if model_dir is not None:
@@ -150,6 +162,7 @@ class StableDiffusionWalkPipeline:
                    unet=_PendingModule("unet", ucfg, u_sd), scheduler=scheduler, safety_checker=safety_checker,
                    feature_extractor=feature_extractor, requires_safety_checker=False, text_config=tcfg)
         pipe.tiled = tiled
+        pipe.synthetic = model_dir is None
         pipe.torch_dtype = torch_dtype or torch.bfloat16
         if device is not None:
             pipe.to(device)
@@ -167,6 +180,7 @@ class StableDiffusionWalkPipeline:
             raise hip.SdvHipError("the HIP engines cannot be moved off the GPU")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(device)      # hip._stream() is the current stream of the CURRENT device
         hip.load()
         if isinstance(self.unet, _PendingModule):
             u, v = self.unet, self.vae
@@ -246,10 +260,17 @@ class StableDiffusionWalkPipeline:
     # the denoise + decode call
     # ------------------------------------------------------------------------------------------
     def _schedule(self, num_inference_steps: int, eta: float):
+        if not hasattr(self.scheduler, "coefficient_table"):
+            raise NotImplementedError(
+                f"{type(self.scheduler).__name__}: the fused HIP denoise step implements DDIM (epsilon / v-prediction, any "
+                "eta) - the scheduler BASELINE.json names.  The reference also accepts PNDM / LMS / Euler / DPM++ "
+                "(stable_diffusion_pipeline.py:71-78); pass stable_diffusion_videos_amd.DDIMScheduler(...) instead.")
         self.scheduler.set_timesteps(num_inference_steps)
         ts = tuple(int(t) for t in self.scheduler.timesteps)
         key = (ts, float(eta), self.scheduler.config.prediction_type)
         if key not in self._sched_cache:
+            while len(self._sched_cache) >= 8:
+                self._sched_cache.pop(next(iter(self._sched_cache)))
             coefs = self.scheduler.coefficient_table(eta).to(self.device)
             self.unet.prepare_timesteps(ts)
             tables = [r.bias_table for r in self.unet.res]
@@ -262,7 +283,13 @@ class StableDiffusionWalkPipeline:
     def _graph_entry(self, key: tuple, nimg: int, B: int, h: int, w: int, cfg: bool, guidance: float, coefs, eta_noise):
         """Static buffers + a captured hipGraph of ONE denoise step (UNet forward + CFG/DDIM update + step++)."""
         if key in self._graphs:
+            self._graphs[key] = self._graphs.pop(key)          # most recently used last
             return self._graphs[key]
+        while len(self._graphs) >= self.max_cached_graphs:     # every captured step owns a multi-GB private pool
+            old_key = next(iter(self._graphs))
+            ent = self._graphs.pop(old_key)
+            ent["graph"] = None
+            del ent
         dev = self.device
         C = self.unet.cfg.in_channels
         ent = {
@@ -362,13 +389,32 @@ class StableDiffusionWalkPipeline:
         latents = latents.to(self.device, F32)
 
         sched_key, coefs, nsteps = self._schedule(num_inference_steps, eta)                       # :394
+        # A ragged last batch (B frames where a graph for B' > B frames is already captured) is padded with copies of its
+        # last frame and replays the big graph: a second capture would own a second multi-GB private pool for one call.
+        B_real = B
+        if self.use_graphs and eta == 0 and callback is None:
+            tail = (h, w, do_cfg, float(guidance_scale), False, int(ctx.shape[1]), self.cfg_shared_prefix, self.tiled)
+            mult = 2 if do_cfg else 1
+            bigger = [k[1] // mult for k in self._graphs if k[0] == sched_key and k[2:] == tail and k[1] // mult > B]
+            if bigger and (B * mult, ) + tail not in {k[1:] for k in self._graphs if k[0] == sched_key}:
+                pad = min(bigger) - B
+                latents = torch.cat([latents, latents[-1:].expand(pad, -1, -1, -1)])
+                if do_cfg:
+                    u, c = ctx[:B], ctx[B:]
+                    ctx = torch.cat([u, u[-1:].expand(pad, -1, -1), c, c[-1:].expand(pad, -1, -1)])
+                else:
+                    ctx = torch.cat([ctx, ctx[-1:].expand(pad, -1, -1)])
+                B += pad
         nimg = 2 * B if do_cfg else B
         eta_noise = None
         if eta > 0:
             gdev = generator.device if generator is not None else torch.device("cpu")
             eta_noise = torch.randn((nsteps, B, h, w, C), generator=generator, device=gdev, dtype=F32).to(self.device)
         self.unet.prepare_context(ctx)
-        gkey = (sched_key, nimg, h, w, do_cfg, float(guidance_scale), eta > 0)
+        # everything a captured step bakes in: pointers of the (nimg, Lc) cross-attention K/V buffers, the shared-prefix
+        # structure, padding mode, guidance scale, schedule
+        gkey = (sched_key, nimg, h, w, do_cfg, float(guidance_scale), eta > 0, int(ctx.shape[1]), self.cfg_shared_prefix,
+                self.tiled)
         ent = self._graph_entry(gkey, nimg, B, h, w, do_cfg, float(guidance_scale), coefs, eta_noise)
         if eta > 0:
             ent.setdefault("noise", eta_noise)
@@ -388,18 +434,18 @@ class StableDiffusionWalkPipeline:
             if callback is not None and i % callback_steps == 0:                                  # :429
                 callback(i, int(self.scheduler.timesteps[i]), hip.nhwc_to_nchw(ent["latents"]))
         if kwargs.get("return_latents", False):
-            return hip.nhwc_to_nchw(ent["latents"])
+            return hip.nhwc_to_nchw(ent["latents"])[:B_real]
         # "numpy_u8": rounded uint8 NHWC array, no PIL objects; "u8_cuda": the same array left in HBM (upsampler input)
         want_float = output_type not in ("pil", "numpy_u8", "u8_cuda")
         u8, f32 = self.vae.decode(ent["latents"], want_float=want_float)                         # :432-435
         if output_type == "u8_cuda":
-            image = u8
+            image = u8[:B_real]
         elif want_float:
-            image = f32.cpu().numpy()                                                             # :438
+            image = f32[:B_real].cpu().numpy()                                                    # :438
         else:
-            image = u8.cpu().numpy()
+            image = u8[:B_real].cpu().numpy()
         t_done = time.perf_counter()
-        self.last_timings = {"prepare_s": t_prep - t_start, "denoise_decode_s": t_done - t_prep, "frames": B}
+        self.last_timings = {"prepare_s": t_prep - t_start, "denoise_decode_s": t_done - t_prep, "frames": B_real}
         has_nsfw = None
         if self.safety_checker is not None:
             raise NotImplementedError("safety_checker is outside the hot path; pass safety_checker=None")
@@ -444,7 +490,8 @@ class StableDiffusionWalkPipeline:
                          width: Optional[int] = None, upsample: bool = False, batch_size: int = 1,
                          image_file_ext: str = ".png", T: np.ndarray = None, skip: int = 0, negative_prompt: str = None,
                          step: Optional[Tuple[int, int]] = None, stop: Optional[int] = None):
-        """Reference :481-554 (``stop`` is the extra upper frame bound used for frame sharding)."""
+        """Reference :481-554 (``stop`` is the extra upper frame bound used for frame sharding: frames [skip, stop) of the
+        clip are generated and written under their own indices)."""
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         save_path = Path(save_path)
@@ -505,7 +552,9 @@ class StableDiffusionWalkPipeline:
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         rank, world_size = parallel.world()
         output_path = Path(output_dir)
-        name = name or time.strftime("%Y%m%d-%H%M%S")
+        # one name for all ranks: they reach this line seconds apart (weight broadcast, engine build), so a per-rank
+        # timestamp would scatter the shards over several directories
+        name = parallel.broadcast_object(name or time.strftime("%Y%m%d-%H%M%S"))
         save_path_root = output_path / name
         save_path_root.mkdir(parents=True, exist_ok=True)
         output_filepath = save_path_root / f"{name}.mp4"
@@ -537,29 +586,43 @@ class StableDiffusionWalkPipeline:
             audio_start_sec = data["audio_start_sec"]
             negative_prompt = data.get("negative_prompt", None)
 
-        # pass 1: what has to be generated (resume logic :741-753, quirk at :750 kept)
+        # pass 1: what has to be generated.  The reference resumes at "last frame on disk + 1" (:741-753), which is only
+        # right for ONE sequential writer; here frames are sharded over ranks and written by a thread pool, so a killed run
+        # leaves holes (rank 0 died at frame 20 of its block, rank 1 at frame 70 of its own).  Resume therefore regenerates
+        # exactly the frames whose file is missing or empty (frames are renamed into place only when complete) - for the
+        # reference's own on-disk states this is the same set, except that its :750 quirk (a clip with exactly one missing
+        # frame is skipped and stays incomplete) is not reproduced.
         clips = []
         for i, (prompt_a, prompt_b, seed_a, seed_b, num_step) in enumerate(
                 zip(prompts, prompts[1:], seeds, seeds[1:], num_interpolation_steps)):
             save_path = save_path_root / f"{name}_{i:06d}"
             step_output_filepath = save_path / f"{name}_{i:06d}.mp4"
-            skip = 0
+            todo = list(range(num_step))
             if resume:
                 if step_output_filepath.exists():
                     print(f"Skipping {save_path} because frames already exist")
                     continue
-                existing_frames = sorted(save_path.glob(f"*{image_file_ext}"))
-                if existing_frames:
-                    skip = int(existing_frames[-1].stem[-6:]) + 1
-                    if skip + 1 >= num_step:
-                        print(f"Skipping {save_path} because frames already exist")
-                        continue
-                    print(f"Resuming {save_path.name} from frame {skip}")
+                have = set()
+                for f in save_path.glob(f"frame*{image_file_ext}"):
+                    digits = f.stem[len("frame"):]
+                    if len(digits) == 6 and digits.isdigit() and f.stat().st_size > 0:
+                        have.add(int(digits))
+                todo = [k for k in range(num_step) if k not in have]
+                if not todo:
+                    print(f"Skipping {save_path} because frames already exist")
+                    continue
+                if have:
+                    print(f"Resuming {save_path.name}: {len(todo)} of {num_step} frames missing (first {todo[0]})")
             clips.append(dict(i=i, prompt_a=prompt_a, prompt_b=prompt_b, seed_a=seed_a, seed_b=seed_b,
-                              num_step=num_step, skip=skip, save_path=save_path, mp4=step_output_filepath))
+                              num_step=num_step, todo=todo, save_path=save_path, mp4=step_output_filepath))
         if world_size > 1:
+            # every rank must shard the SAME work list: rank 0's view of the directory decides
+            todo_lists = parallel.broadcast_object([c["todo"] for c in clips] if rank == 0 else None)
+            if len(todo_lists) == len(clips):
+                for c, t in zip(clips, todo_lists):
+                    c["todo"] = t
             parallel.barrier()      # every rank has looked at the directory before anyone writes new frames
-        shares = parallel.partition_frames([c["num_step"] for c in clips], world_size, rank, [c["skip"] for c in clips])
+        shares = parallel.partition_frame_list([c["todo"] for c in clips], world_size, rank)
 
         # pass 2: generate this rank's frames
         self._writer = FrameWriter()

@@ -64,9 +64,19 @@ class FrameWriter:
 
     @staticmethod
     def _save(image, path: Path, upsampler):
+        """Encode into ``<name>.part`` and rename: a killed run never leaves a truncated frame that ``resume`` (which
+        only looks at complete ``frame%06d`` files) or the video mux would pick up."""
+        from PIL import Image
         if upsampler is not None:
             image = upsampler(image)
-        image.save(path)
+        path = Path(path)
+        fmt = Image.registered_extensions().get(path.suffix.lower())
+        if fmt is None:
+            image.save(path)                     # unknown extension: let PIL raise its own error
+            return
+        tmp = path.with_name(path.name + ".part")
+        image.save(tmp, format=fmt)
+        os.replace(tmp, path)
 
     def submit(self, image, path: Path, upsampler=None):
         self.pending.append(self.pool.submit(self._save, image, path, upsampler))

@@ -301,7 +301,7 @@ def upconv_phase_w(w: torch.Tensor, device) -> torch.Tensor:
     co, ci = w.shape[:2]
     wf = w.to(torch.float32)
     groups = {0: ([0], [1, 2]), 1: ([0, 1], [2])}          # phase -> 3x3 tap indices summed into 2x2 tap 0 / tap 1
-    out = torch.empty((2, 2, co, 2, 2, ci), dtype=torch.float32)
+    out = torch.empty((2, 2, co, 2, 2, ci), dtype=torch.float32, device=wf.device)
     for py in (0, 1):
         for px in (0, 1):
             for ty in (0, 1):

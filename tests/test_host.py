@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu(hip):
     a.M = a.N = 64
     a.K = 96
     assert lib.sdv_gemm_bf16(ctypes.byref(a), None) == -1 and b"multiple of 64" in lib.sdv_last_error()
-    assert lib.sdv_attention_bf16(1, 1, 1, 1, 1, 1, 64, 64, 48, 64, 64, 64, 64, 1.0, 0, None) == -1
+    assert lib.sdv_attention_bf16(1, 1, 1, 1, 1, 1, 64, 64, 48, 64, 64, 64, 64, 1.0, 0, 0, None) == -1
     assert b"unsupported head dim" in lib.sdv_last_error()
 
 
@@ -165,6 +165,47 @@ def test_partition_frames_covers_every_frame_once():
             expect = [(i, k) for i, c in enumerate(counts) for k in range(sk[i], c)]
             assert seen == expect                  # contiguous, ordered, disjoint, complete
             assert max(sizes) - min(sizes) <= 1    # balanced
+
+
+def test_partition_frame_list_with_holes():
+    """Resume after a multi-rank crash: rank 0 died at frame 20 of its block [0, 50), rank 1 at frame 70 of
+    [50, 100): the work list is the set of MISSING frames, and every one of them is generated exactly once."""
+    from stable_diffusion_videos_amd.parallel import partition_frame_list
+    todo = [[k for k in range(100) if not (k <= 20 or 50 <= k <= 70)], [], list(range(3))]
+    seen = []
+    for rank in range(3):
+        for clip, a, b in partition_frame_list(todo, 3, rank):
+            seen += [(clip, k) for k in range(a, b)]
+    assert sorted(seen) == sorted((c, k) for c, fr in enumerate(todo) for k in fr) and len(seen) == len(set(seen))
+    assert (0, 21) in seen and (0, 49) in seen and (0, 71) in seen and (0, 20) not in seen
+
+
+def test_no_silent_synthetic_fallback_and_scheduler_error(tmp_path):
+    """from_pretrained() of something that is neither a local directory nor an explicit synthetic request raises (ADVICE:
+    a hub id or typo used to return a pipeline of random weights silently); non-DDIM schedulers get a clear error."""
+    from types import SimpleNamespace
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline as P
+    with pytest.raises(FileNotFoundError, match="SYNTHETIC"):
+        P.from_pretrained("CompVis/stable-diffusion-v1-4")
+    with pytest.raises(FileNotFoundError):
+        P.from_pretrained(str(tmp_path / "typo"))
+    pipe = P.from_pretrained("CompVis/stable-diffusion-v1-4", arch="tiny")
+    assert pipe.synthetic is True
+    assert P.from_pretrained("somewhere", synthetic=True, arch="tiny").synthetic
+    pipe.scheduler = SimpleNamespace(config=SimpleNamespace(steps_offset=1, clip_sample=False))     # "LMSDiscreteScheduler"
+    with pytest.raises(NotImplementedError, match="DDIM"):
+        pipe._schedule(50, 0.0)
+
+
+def test_frame_writer_renames_complete_files_into_place(tmp_path):
+    from PIL import Image
+    from stable_diffusion_videos_amd.utils import FrameWriter
+    w = FrameWriter(workers=2)
+    for k in range(4):
+        w.submit(Image.fromarray(np.full((8, 8, 3), k, dtype=np.uint8)), tmp_path / f"frame{k:06d}.png")
+    w.close()
+    assert sorted(p.name for p in tmp_path.iterdir()) == [f"frame{k:06d}.png" for k in range(4)]
+    assert np.asarray(Image.open(tmp_path / "frame000003.png"))[0, 0, 0] == 3
 
 
 def test_hash_tokenizer_call_shape():

@@ -375,6 +375,89 @@ def test_cfg_shared_prefix_is_exact(hip, dev):
         assert float((a[:2] - a[2:]).abs().max()) > 1e-3      # the two halves really differ (different text context)
 
 
+def _run_ranks(world, backend, args, extra_env=None, timeout=600):
+    """Launch ``world`` ranks of tests/dist_walk_worker.py (all on cuda:0) and wait for them."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SDV_DIST_BACKEND=backend, SDV_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).parent / "dist_walk_worker.py"), *args], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return outs
+
+
+def _frames_of(root):
+    return {str(f.relative_to(root)): f.read_bytes() for f in sorted(Path(root).rglob("frame*.png"))}
+
+
+def test_two_rank_walk_writes_the_same_frames_as_one_rank(hip, dev, tmp_path):
+    """Frame-sharded data parallelism (the reference's only multi-device strategy is
+    flax_stable_diffusion_pipeline.py:568-597): 2 ranks on ONE GPU (gloo control plane, every rank's kernels on cuda:0)
+    write exactly the frame files a 1-rank walk writes, byte for byte - including the auto-generated run name (broadcast
+    from rank 0) and a resume after a crash that left HOLES in both ranks' blocks."""
+    one = tmp_path / "one"
+    two = tmp_path / "two"
+    _run_ranks(1, "gloo", [str(one), "w"])
+    outs = _run_ranks(2, "gloo", [str(two), "w"])
+    assert all("backend gloo done" in o for o in outs)
+    a, b = _frames_of(one / "w"), _frames_of(two / "w")
+    assert sorted(a) == sorted(b) and len(a) == 9
+    assert a == b, "2-rank frames differ from the 1-rank frames"
+    assert (two / "w" / "prompt_config.json").exists()
+    # auto name: both ranks must land in ONE directory
+    auto = tmp_path / "auto"
+    _run_ranks(2, "gloo", [str(auto), "-"])
+    dirs = [d for d in auto.iterdir() if d.is_dir()]
+    assert len(dirs) == 1 and len(_frames_of(dirs[0])) == 9
+    # crash with holes: rank 0's block lost frames 1-2 of clip 0, rank 1's block lost frame 1 of clip 1, plus a truncated
+    # (zero-byte) frame and a stale .part file
+    for rel in ("w_000000/frame000001.png", "w_000000/frame000002.png", "w_000001/frame000001.png"):
+        (two / "w" / rel).unlink()
+    (two / "w" / "w_000001" / "frame000003.png").write_bytes(b"")
+    (two / "w" / "w_000000" / "frame000004.png.part").write_bytes(b"junk")
+    _run_ranks(2, "gloo", [str(two), "w", "resume"])
+    c = _frames_of(two / "w")
+    assert c == a, "resume after a crash with holes did not restore every frame"
+
+
+def test_rccl_weight_broadcast_path_runs_with_one_rank(hip, dev, tmp_path):
+    """The RCCL (backend "nccl") code path - process-group init with a device id, the two packed weight broadcasts, the
+    device-side re-layout of the received buffers, barriers - executed with world_size 1 (the pool has 1-GPU boxes); the
+    frames equal those of a run without any process group."""
+    plain = tmp_path / "plain"
+    rccl = tmp_path / "rccl"
+    _run_ranks(1, "gloo", [str(plain), "w"])
+    outs = _run_ranks(1, "nccl", [str(rccl), "w"], extra_env={"SDV_DIST_INIT": "1"})
+    assert "backend nccl done" in outs[0]
+    assert _frames_of(plain / "w") == _frames_of(rccl / "w")
+
+
+def test_ragged_last_batch_reuses_the_captured_graph(hip, dev, tmp_path):
+    """5 frames at batch_size 4: the 1-frame tail is padded and replays the 4-frame graph (one captured step, one private
+    pool) and still writes the frames a batch_size-1 walk writes."""
+    from PIL import Image
+    pipe = _tiny_pipeline(dev)
+    kw = dict(output_dir=str(tmp_path), fps=3, num_inference_steps=3, height=64, width=64, make_video=False)
+    pipe.walk(["a cat", "a dog"], seeds=[1, 2], num_interpolation_steps=5, name="b4", batch_size=4, **kw)
+    assert len(pipe._graphs) == 1
+    pipe.walk(["a cat", "a dog"], seeds=[1, 2], num_interpolation_steps=5, name="b1", batch_size=1, **kw)
+    for k in range(5):
+        a = np.asarray(Image.open(tmp_path / "b4" / "b4_000000" / f"frame{k:06d}.png")).astype(int)
+        b = np.asarray(Image.open(tmp_path / "b1" / "b1_000000" / f"frame{k:06d}.png")).astype(int)
+        assert np.abs(a - b).max() <= 2, k
+
+
 def test_walk_with_audio_and_video(hip, dev, tmp_path):
     """Mirror of the reference's test_walk_with_audio (tests/test_pipeline.py:53-68): audio-driven T per clip,
     batch_size 16, and the mp4 files of the documented layout (:648-666) exist."""
