@@ -18,6 +18,8 @@ Extra objects in the JSON line:
                algorithmic, padding not counted) x frames/s/GPU; plus `kernels`: per-kernel algorithmic
                TFLOP/s and share of GPU time from a HIP-event-bracketed eager pass (one UNet forward + one VAE
                decode of the same batch) run outside the timed region.
+  attention    the UNet's 64x64-level self-attention: algorithmic / issued TFLOP/s (live) + PMC MFMA-busy share (committed profile)
+  frames_per_sec_incl_png / walk_60_frames   the literal BASELINE config 2 (60 frames) through walk(), PNG files included
   cpu_baseline the CPU oracle (PyTorch eager fp32 restatement of the reference path) timed on this host's cores
                on a bounded sample - 1 CFG UNet forward (2 samples) + 1 VAE decode at full size - and
                extrapolated to 50 steps.
@@ -51,7 +53,11 @@ def parse():
     ap.add_argument("--arch", default="sd14", choices=["sd14", "sd21", "tiny"])
     ap.add_argument("--size", type=int, default=0, help="image size (default: 512 for sd14, 768 for sd21)")
     ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="BASELINE.json configs[] index + 1: 2 = weak-scaled K x B frames per rank (default, the driver's "
+                         "contract); 3 = the literal 8-GPU config: 4 prompts, 240 frames in total, STRONG-scaled over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-walk-pass", action="store_true", help="skip the 60-frame walk() pass (frames/s including PNG files)")
     ap.add_argument("--no-kernel-pass", action="store_true")
     return ap.parse_args()
 
@@ -143,6 +149,56 @@ def kernel_pass(pipe, embeds, noise, size, steps):
     out["unet_forward_event_ms"] = round(tot_u, 3)
     out["unet_forward_wall_ms_eager"] = round(t_unet * 1e3, 3)
     out["vae_decode_event_ms"] = round(tot_v, 3)
+    out["_unet_shapes"] = prof_u.by_shape()
+    return out
+
+
+def pmc_profile():
+    """Counters of the committed rocprofv3 --pmc passes over one UNet forward at this bench's batch
+    (profiles/round2_pmc_unet_b64.csv, made by tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  Returns {kernel substring: {counter: mean per launch}} or {} when the file is not there."""
+    path = ROOT / "profiles" / "round2_pmc_unet_b64.csv"
+    if not path.exists():
+        return {}
+    import csv
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        a = acc.setdefault((r["kernel"], r["counter"]), [0.0, 0])
+        a[0] += float(r["mean"]) * int(r["dispatches"])
+        a[1] += int(r["dispatches"])
+    out = {}
+    for (k, c), (tot, n) in acc.items():
+        out.setdefault(k, {})[c] = tot / max(n, 1)
+    return out
+
+
+def dominant_kernel_traffic(pmc):
+    """HBM-side bytes per launch of the dominant kernel (the 256x320 implicit-GEMM conv), averaged over its launches in
+    one UNet forward: FETCH_SIZE [KiB] x 2 (gfx950 correction) + WRITE_SIZE [KiB]."""
+    for k, c in pmc.items():
+        if k.startswith("igemm_kernel<4, 2, 2, 5, 64, true") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return {"kernel": k, "fetch_bytes": round(c["FETCH_SIZE"] * 2 * 1024), "write_bytes": round(c["WRITE_SIZE"] * 1024),
+                    "source": "profiles/round2_pmc_unet_b64.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    return None
+
+
+def attention_object(shapes, pmc):
+    """UNet 64x64-level self-attention (dh 40, 4096 tokens): algorithmic and issued TFLOP/s + PMC MFMA-busy share."""
+    row = next((r for r in shapes if r["kind"] == "attention" and r.get("dh") == 40 and r.get("Lk") == r.get("Lq") == 4096
+                and r.get("B", 0) > 64), None) or next((r for r in shapes if r["kind"] == "attention" and r.get("dh") == 40
+                                                        and r.get("Lk") == 4096), None)
+    if row is None:
+        return None
+    alg = row["tflops"]
+    out = {"shape": {k: row[k] for k in ("B", "H", "Lq", "Lk", "dh")}, "algorithmic_tflops": alg,
+           # the kernel pads dh 40 -> 48 for Q.K^T and -> 64 rows for P.V: (48 + 64) / (40 + 40) of the algorithmic MFMA work
+           "issued_tflops": round(alg * 1.4, 1), "frac_of_mfma_peak_algorithmic": round(alg / MFMA_PEAK_TFLOPS, 3),
+           "frac_of_mfma_peak_issued": round(alg * 1.4 / MFMA_PEAK_TFLOPS, 3)}
+    for k, c in pmc.items():
+        if k.startswith("attention_kernel<40, 2") and "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            # busy cycles summed over 1024 SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs
+            out["mfma_busy_pmc"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+            out["mfma_busy_source"] = "profiles/round2_pmc_unet_b64.csv"
     return out
 
 
@@ -195,46 +251,82 @@ def main():
     cfgs_for_cpu = (pipe.unet.config, pipe.vae.config)
     pipe.to(dev)                                           # weight relayout (+ RCCL broadcast when world > 1)
 
-    # the walk: 2 prompts, seeds 42/1337; rank r owns frames [r*K*B, (r+1)*K*B) of world*K*B
-    total_frames = world * (args.steps + args.warmup) * B
-    T_all = np.linspace(0.0, 1.0, total_frames)
-    my_T = T_all[rank * (args.steps + args.warmup) * B:(rank + 1) * (args.steps + args.warmup) * B]
     h = size // 8
-    gen = pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), my_T, B)
+    if args.config == 3:
+        # BASELINE.json configs[2]: 4 prompts, [80, 80, 80] = 240 interpolated frames in TOTAL, frame-sharded over the ranks
+        # (30 per rank on 8 GPUs): strong scaling.  Every rank takes its contiguous block of the flattened (clip, frame) list
+        # exactly as walk() does and runs it in batches of at most B frames (one untimed warm-up batch first).
+        prompts, seeds, counts = ["a cat", "a dog", "a horse", "a cow"], [42, 1337, 2022, 4321], [80, 80, 80]
+        shares = parallel.partition_frames(counts, world, rank)
+        work = []
+        for ci, a, b in shares:
+            T = np.linspace(0.0, 1.0, counts[ci])[a:b]
+            for _, embeds, noise in pipe.generate_inputs(prompts[ci], prompts[ci + 1], seeds[ci], seeds[ci + 1], (1, 4, h, h), T, B):
+                work.append((embeds, noise))
+        my_T = np.linspace(0.0, 1.0, B)
 
-    def one_step():
-        _, embeds, noise = next(gen)
-        out = pipe(latents=noise, text_embeddings=embeds, height=size, width=size,
-                   num_inference_steps=args.inference_steps, guidance_scale=7.5, eta=0.0, output_type="numpy_u8")
-        return out["images"]                               # uint8 NHWC frames on the host
+        def run(embeds, noise):
+            return pipe(latents=noise, text_embeddings=embeds, height=size, width=size, num_inference_steps=args.inference_steps,
+                        guidance_scale=7.5, eta=0.0, output_type="numpy_u8")["images"]
 
-    for _ in range(args.warmup):
-        last = one_step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = one_step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    elapsed = time.perf_counter() - t0
+        last = run(*max(work, key=lambda w: w[0].shape[0]))       # warm-up: captures the graph of the largest batch
+        torch.cuda.synchronize()
+        parallel.barrier()
+        t0 = time.perf_counter()
+        for embeds, noise in work:
+            last = run(embeds, noise)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        elapsed = time.perf_counter() - t0
+        steps_done = len(work)
+        frames = sum(counts)
+        workload = (f"{args.arch} walk, 4 prompts, {frames} interpolated frames in total ({frames // world} per rank, batches of "
+                    f"<= {B}), {size}x{size}, {args.inference_steps} DDIM steps, CFG 7.5")
+        scaling = "strong"
+    else:
+        # the walk: 2 prompts, seeds 42/1337; rank r owns frames [r*K*B, (r+1)*K*B) of world*K*B
+        total_frames = world * (args.steps + args.warmup) * B
+        T_all = np.linspace(0.0, 1.0, total_frames)
+        my_T = T_all[rank * (args.steps + args.warmup) * B:(rank + 1) * (args.steps + args.warmup) * B]
+        gen = pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), my_T, B)
+
+        def one_step():
+            _, embeds, noise = next(gen)
+            out = pipe(latents=noise, text_embeddings=embeds, height=size, width=size,
+                       num_inference_steps=args.inference_steps, guidance_scale=7.5, eta=0.0, output_type="numpy_u8")
+            return out["images"]                               # uint8 NHWC frames on the host
+
+        for _ in range(args.warmup):
+            last = one_step()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = one_step()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        elapsed = time.perf_counter() - t0
+        steps_done = args.steps
+        frames = world * args.steps * B
+        workload = (f"{args.arch} walk, 2 prompts, {frames} interpolated frames ({args.steps} steps x {B} frames x {world} GPU; "
+                    f"BASELINE config 2 names 60 frames - this is the same walk with more frames, see `walk_60_frames` for the "
+                    f"literal one), {size}x{size}, {args.inference_steps} DDIM steps, CFG 7.5")
+        scaling = "weak"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    frames = world * args.steps * B
     fps = frames / elapsed
     flop_per_frame = FLOP_PER_FRAME.get(args.arch)
     result = {
         "metric": "interpolated frames/sec (512x512, 50 DDIM steps)" if args.arch == "sd14" and size == 512 and
         args.inference_steps == 50 else f"interpolated frames/sec ({size}x{size}, {args.inference_steps} DDIM steps)",
-        "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+        "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / max(steps_done, 1), 2), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random-init SD weights, hash-tokenised prompts)",
-        "config": {"workload": f"{args.arch} walk, 2 prompts, {frames} interpolated frames ({args.steps} steps x "
-                               f"{B} frames x {world} GPU), {size}x{size}, {args.inference_steps} DDIM steps, CFG 7.5",
-                   "batch_size": B, "frames": frames, "parallelism": f"frame-sharded dp{world}", "hipgraph": pipe.use_graphs},
+        "config": {"workload": workload, "batch_size": B, "frames": frames, "parallelism": f"frame-sharded dp{world}",
+                   "hipgraph": pipe.use_graphs, "baseline_config": args.config},
     }
     if rank == 0:
         if flop_per_frame and args.inference_steps == 50:
@@ -247,7 +339,42 @@ def main():
                                   "frac": None, "traffic": None}
         if not args.no_kernel_pass:
             _, embeds, noise = next(pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), my_T[:B], B))
-            result["roofline"]["kernels"] = kernel_pass(pipe, embeds, noise, size, args.inference_steps)
+            kp = kernel_pass(pipe, embeds, noise, size, args.inference_steps)
+            shapes = kp.pop("_unet_shapes")
+            result["roofline"]["kernels"] = kp
+            pmc = pmc_profile() if (args.arch == "sd14" and size == 512) else {}
+            # dominant kernel = the implicit-GEMM conv (largest share of GPU time): algorithmic TFLOP/s live (HIP events),
+            # HBM-side traffic per launch from the committed PMC passes of the same forward
+            dom = kp.get("unet.conv3x3")
+            if dom:
+                result["roofline"]["dominant_kernel"] = {"name": "igemm_kernel (conv3x3, 256x320 tile)", "bound": "mfma",
+                                                         "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                         "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                                                         "avg_launch_us": dom["avg_us"], "share_of_unet_time": dom["share"]}
+                tr = dominant_kernel_traffic(pmc)
+                if tr:
+                    result["roofline"]["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
+                    result["roofline"]["dominant_kernel"]["traffic"] = tr
+            att = attention_object(shapes, pmc)
+            if att:
+                result["attention"] = att
+        if world == 1 and args.config == 2 and not args.no_walk_pass:
+            # the LITERAL BASELINE config 2 through the public API: walk() of 2 prompts, 60 interpolated frames, files and all
+            # (lerp / slerp, 50-step loop, VAE, D2H, PNG encode + write by the asynchronous writer pool); make_video=False
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="sdv_bench_walk_")
+            try:
+                t1 = time.perf_counter()
+                pipe.walk(["a cat", "a dog"], seeds=[42, 1337], num_interpolation_steps=60, output_dir=tmp, name="w",
+                          batch_size=B, height=size, width=size, num_inference_steps=args.inference_steps, make_video=False)
+                dt = time.perf_counter() - t1
+                n_png = len(list(Path(tmp).rglob("frame*.png")))
+                result["frames_per_sec_incl_png"] = round(n_png / dt, 4)
+                result["walk_60_frames"] = {"frames": n_png, "seconds": round(dt, 3), "batch_size": B,
+                                            "includes": "text encoder, interpolation, denoise, VAE, D2H, PNG encode + write"}
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
         # host-side PNG encode rate (outside `value`; the reference pays it serially at :553)
         from PIL import Image
         import io

@@ -4,6 +4,7 @@
 Public names mirror /root/reference/stable_diffusion_videos/__init__.py:99-119 for the parts of the
 package that are on (or directly around) the walk path.
 """
+from . import ops  # noqa: F401  (registers torch.ops.sdv.*)
 from .image_generation import generate_images
 from .pipeline import StableDiffusionPipelineOutput, StableDiffusionWalkPipeline
 from .scheduler import DDIMScheduler

@@ -208,6 +208,27 @@ def test_frame_writer_renames_complete_files_into_place(tmp_path):
     assert np.asarray(Image.open(tmp_path / "frame000003.png"))[0, 0, 0] == 3
 
 
+def test_torch_custom_ops_are_registered_with_fake_kernels(hip):
+    """north_star: "... HIP kernels through PyTorch-ROCm custom ops" - torch.ops.sdv.* exist, carry schemas and meta
+    (FakeTensor) implementations, and have NO CPU kernel (a CPU tensor raises, it does not fall back)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import stable_diffusion_videos_amd  # noqa: F401
+    from stable_diffusion_videos_amd import ops
+    for name in ops.OPS:
+        assert hasattr(torch.ops.sdv, name), name
+    with FakeTensorMode():
+        x = torch.empty((128, 64), dtype=torch.bfloat16)
+        w = torch.empty((256, 64), dtype=torch.bfloat16)
+        assert torch.ops.sdv.linear(x, w).shape == (128, 256)
+        assert torch.ops.sdv.linear(x, w, None, None, 1).shape == (128, 128)               # GEGLU halves N
+        assert torch.ops.sdv.conv3x3(x, torch.empty((32, 576), dtype=torch.bfloat16), None, 2, 8, 8, 2).shape == (32, 32)
+        assert torch.ops.sdv.upsample_conv3x3(x, torch.empty((4 * 48, 256), dtype=torch.bfloat16), None, 2, 8, 8).shape == (512, 48)
+        q = torch.empty((2, 100, 80), dtype=torch.bfloat16)
+        assert torch.ops.sdv.attention(q, q, torch.empty((2, 80, 128), dtype=torch.bfloat16), 2, 0.158).shape == (2, 100, 80)
+    with pytest.raises(hip.SdvHipError, match="GPU"):
+        torch.ops.sdv.linear(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+
+
 def test_hash_tokenizer_call_shape():
     from stable_diffusion_videos_amd import config
     from stable_diffusion_videos_amd.text import HashTokenizer

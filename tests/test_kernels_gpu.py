@@ -602,3 +602,29 @@ def test_layout_helpers(hip, dev):
     assert torch.equal(hip.nchw_to_nhwc(x), x.permute(0, 2, 3, 1).contiguous())
     assert torch.equal(hip.nhwc_to_nchw(hip.nchw_to_nhwc(x)), x)
     assert torch.equal(hip.f32_to_bf16(x), x.to(BF16))
+
+
+def test_torch_custom_ops_run_the_same_kernels(hip, dev):
+    """torch.ops.sdv.* (stable_diffusion_videos_amd/ops.py) forward to the same C-ABI launches as the ctypes wrappers."""
+    import stable_diffusion_videos_amd  # noqa: F401  (registers the ops)
+    from stable_diffusion_videos_amd.weights import conv_w, upconv_phase_w
+    x, w, b = rnd((256, 128), dev, 90).to(BF16), rnd((192, 128), dev, 91, 128 ** -0.5).to(BF16), rnd((192,), dev, 92)
+    assert torch.equal(torch.ops.sdv.linear(x, w, b), hip.linear(x, w, b))
+    xc = rnd((2 * 8 * 8, 64), dev, 93).to(BF16)
+    wc = rnd((64, 64, 3, 3), dev, 94, 576 ** -0.5)
+    assert torch.equal(torch.ops.sdv.conv3x3(xc, conv_w(wc, dev), None, 2, 8, 8), hip.conv3x3(xc, conv_w(wc, dev), None, nimg=2, H=8, W=8))
+    up = torch.ops.sdv.upsample_conv3x3(xc, upconv_phase_w(wc.cpu(), dev), None, 2, 8, 8)
+    assert up.shape == (2 * 16 * 16, 64) and torch.equal(up, hip.upconv3x3_phase(xc, upconv_phase_w(wc.cpu(), dev), None, nimg=2, H=8, W=8))
+    q, k, v = rnd((2, 100, 80), dev, 95), rnd((2, 77, 80), dev, 96), rnd((2, 77, 80), dev, 97)
+    vt = torch.zeros((2, 80, 128), dtype=BF16, device=dev)
+    vt[:, :, :77] = v.transpose(1, 2).to(BF16)
+    o = torch.ops.sdv.attention(q.to(BF16), k.to(BF16), vt, 2, 40 ** -0.5)
+    assert rel_l2(o.float(), attn_ref(q, k, v, 2, 40 ** -0.5)) < 6e-3
+    g, be = rnd((128,), dev, 98), rnd((128,), dev, 99)
+    assert torch.equal(torch.ops.sdv.layer_norm(x, g, be), hip.layernorm(x, g, be))
+    assert torch.equal(torch.ops.sdv.group_norm(x, g, be, 2, 32, 1e-5, True), hip.groupnorm(x, g, be, nimg=2, HW=128, groups=32, eps=1e-5, silu=True))
+    a, bb = rnd((1, 77, 64), dev, 100), rnd((1, 77, 64), dev, 101)
+    T = torch.tensor([0.0, 0.25, 1.0], device=dev)
+    assert torch.allclose(torch.ops.sdv.lerp_batch(a, bb, T), torch.stack([torch.lerp(a[0], bb[0], float(t)) for t in T]), atol=1e-6)
+    s3 = torch.ops.sdv.slerp_batch(a, bb, T)
+    assert s3.shape == (3, 77, 64) and torch.equal(s3[0], a[0]) and torch.equal(s3[2], bb[0])
