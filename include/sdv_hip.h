@@ -84,9 +84,24 @@ typedef struct sdv_gemm_args {
     uint32_t div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;   /* filled in by sdv_gemm_bf16 (mode 4 row mapping); callers leave 0 */
     int32_t alpha_cols;   /* > 0: alpha multiplies only output columns [0, alpha_cols) (the Q half of a fused [Q | K] projection:
                              q * softmax_scale * log2(e) is rounded to bf16 ONCE, here, not a second time inside the attention) */
+    /* LayerNorm folded into the GEMMs around it (BasicTransformerBlock.norm1/2/3 -> to_q/k/v, ff.net.0): the PRODUCER of the
+     * normalised tensor writes per-row partial (sum, sumsq) of its bf16 outputs to stats_out [batch][M][slots][2]
+     * (slots = sdv_gemm_stats_slots(args)), sdv_rowstats_finalize turns them into (mean, rstd) per row, and the CONSUMER
+     * runs on the UN-normalised tensor with gamma-scaled weights W' = gamma o W:
+     *     LN(x) W^T + b = rstd * (x W'^T - mean * s) + (W beta + b),   s[n] = sum_k W'[n][k]   (pass W beta + b as `bias`)
+     * ln_side 1: ln_stats [batch][M][2] belongs to the output rows, ln_s [N] to the columns;
+     * ln_side 2: ln_stats [batch][N][2] belongs to the output columns, ln_s [M] to the rows (the transposed V^T projection). */
+    const float* ln_stats;
+    const float* ln_s;
+    float* stats_out;
+    int32_t ln_side;
+    int32_t stats_p;      /* filled in by sdv_gemm_bf16 */
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
+int sdv_gemm_stats_slots(const sdv_gemm_args* args);
+/* partial (sum, sumsq) [rows][slots][2] -> (mean, rstd) [rows][2] over C channels */
+int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, int32_t C, float eps, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flash-style attention, softmax(Q K^T * scale) V, never materialising the score matrix.

@@ -35,7 +35,9 @@ namespace {
 // raw `s_barrier`): three tiles of loads per CU in flight keep HBM busy for the K <= 640 projections, the barrier sits in
 // the MIDDLE of a tile's MFMAs (fragments of the second k-step are already in registers), and the DMA issue and every
 // fragment read are slotted behind MFMAs instead of in front of them.
-template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST = 2>
+// FEAT compiles ONE of the LayerNorm-fold features into the epilogue (dense GEMMs of the transformer blocks only - each costs
+// registers the 256-row tiles do not have to spare): 1 = ln_side 1 consumer, 2 = ln_side 2 consumer, 3 = stats_out producer.
+template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST = 2, int FEAT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * WM * WN / 4)) void igemm_kernel(const sdv_gemm_args p) {
     constexpr int NWV = WM * WN;            // waves per workgroup (4 or 8)
     // The extra activations (epi 3 LeakyReLU, 4 quick_gelu, 5 GELU: RRDBNet / CLIP text encoder) are compiled into the
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                              (((p.sC | p.sR) & 7) == 0);
         if (aligned) {
             float* stg = (float*)smem + wave * (32 * 64);
+            float* rowacc = (float*)smem + NWV * (32 * 64) + wave * 64;   // (sum, sumsq) of this wave's 32 rows (stats_out)
             __syncthreads();  // every wave has left the K loop: the tile buffers may be overwritten
             // one pass: n-tiles [nt0, nt0+ntc) of m-tile mt -> OC output columns starting at ocol
             auto pass = [&](auto oc_tag, int mt, int nt0, int ocol) {
@@ -479,6 +482,20 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 }
                 const int mrow = mbase + l31;
                 const float bm_ = (bias && p.bias_mode == 2 && mrow < p.M) ? bias[mrow] : 0.f;
+                // LayerNorm folded into this GEMM (sdv_hip.h "ln_side"): the weights were pre-multiplied by gamma, so
+                //   LN(x) W^T = rstd * (x (gamma o W)^T - mean * s) + (W beta + b),  s = row sums of gamma o W
+                // side 1: (mean, rstd) belong to the output ROW (this lane's m), s to the output column;
+                // side 2 (the transposed V^T projection): (mean, rstd) belong to the output COLUMN, s to the row.
+                float ln_mu = 0.f, ln_rs = 1.f, ln_sm = 0.f;
+                constexpr int ln_side = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
+                float* const stats_out = FEAT == 3 ? p.stats_out : nullptr;
+                if (ln_side == 1 && mrow < p.M) {
+                    const float2 st = *(const float2*)(p.ln_stats + 2 * (bz * p.M + mrow));
+                    ln_mu = st.x;
+                    ln_rs = st.y;
+                } else if (ln_side == 2 && mrow < p.M) {
+                    ln_sm = p.ln_s[mrow];
+                }
                 if (geglu) {
                     // W rows are interleaved [16 value | 16 gate] per 32-row MFMA tile: accumulator quads g and g+2 of
                     // a lane hold the value and the gate of the SAME 4 channels -> 16 output columns per n-tile
@@ -493,11 +510,17 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                                 bv = *(const float4*)(bias + nv);
                                 bg = *(const float4*)(bias + nv + 16);
                             }
+                            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = sv;
+                            if (ln_side == 1 && nv + 19 < p.N) {
+                                sv = *(const float4*)(p.ln_s + nv);
+                                sg = *(const float4*)(p.ln_s + nv + 16);
+                            }
+                            const float ar = alpha * ln_rs;
                             float4 o;
-                            o.x = (acc[nt][mt][4 * g + 0] * alpha + bv.x) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 0] * alpha + bg.x);
-                            o.y = (acc[nt][mt][4 * g + 1] * alpha + bv.y) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 1] * alpha + bg.y);
-                            o.z = (acc[nt][mt][4 * g + 2] * alpha + bv.z) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 2] * alpha + bg.z);
-                            o.w = (acc[nt][mt][4 * g + 3] * alpha + bv.w) * gelu_erf_f(acc[nt][mt][4 * (g + 2) + 3] * alpha + bg.w);
+                            o.x = ((acc[nt][mt][4 * g + 0] - ln_mu * sv.x) * ar + bv.x) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 0] - ln_mu * sg.x) * ar + bg.x);
+                            o.y = ((acc[nt][mt][4 * g + 1] - ln_mu * sv.y) * ar + bv.y) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 1] - ln_mu * sg.y) * ar + bg.y);
+                            o.z = ((acc[nt][mt][4 * g + 2] - ln_mu * sv.z) * ar + bv.z) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 2] - ln_mu * sg.z) * ar + bg.z);
+                            o.w = ((acc[nt][mt][4 * g + 3] - ln_mu * sv.w) * ar + bv.w) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 3] - ln_mu * sg.w) * ar + bg.w);
                             const int chunk = j * 4 + 2 * g + lhi;
                             *(float4*)(stg + l31_p * 64 + ((chunk ^ (l31_p & 7)) << 2)) = o;
                         }
@@ -518,10 +541,31 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                             }
                             float4 o;
                             const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
-                            o.x = acc[nt][mt][4 * g4 + 0] * al + bv.x;
-                            o.y = acc[nt][mt][4 * g4 + 1] * al + bv.y;
-                            o.z = acc[nt][mt][4 * g4 + 2] * al + bv.z;
-                            o.w = acc[nt][mt][4 * g4 + 3] * al + bv.w;
+                            if (ln_side == 1) {
+                                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (nb + 3 < p.N) s4 = *(const float4*)(p.ln_s + nb);
+                                const float ar = al * ln_rs;
+                                o.x = (acc[nt][mt][4 * g4 + 0] - ln_mu * s4.x) * ar + bv.x;
+                                o.y = (acc[nt][mt][4 * g4 + 1] - ln_mu * s4.y) * ar + bv.y;
+                                o.z = (acc[nt][mt][4 * g4 + 2] - ln_mu * s4.z) * ar + bv.z;
+                                o.w = (acc[nt][mt][4 * g4 + 3] - ln_mu * s4.w) * ar + bv.w;
+                            } else if (ln_side == 2) {
+                                float4 st0 = make_float4(0.f, 1.f, 0.f, 1.f), st1 = st0;   // (mean, rstd) of columns nb .. nb+3
+                                if (nb + 3 < p.N) {
+                                    const float* st = p.ln_stats + 2 * (bz * p.N + nb);
+                                    st0 = *(const float4*)(st);
+                                    st1 = *(const float4*)(st + 4);
+                                }
+                                o.x = (acc[nt][mt][4 * g4 + 0] - st0.x * ln_sm) * (st0.y * al) + bv.x;
+                                o.y = (acc[nt][mt][4 * g4 + 1] - st0.z * ln_sm) * (st0.w * al) + bv.y;
+                                o.z = (acc[nt][mt][4 * g4 + 2] - st1.x * ln_sm) * (st1.y * al) + bv.z;
+                                o.w = (acc[nt][mt][4 * g4 + 3] - st1.z * ln_sm) * (st1.w * al) + bv.w;
+                            } else {
+                                o.x = acc[nt][mt][4 * g4 + 0] * al + bv.x;
+                                o.y = acc[nt][mt][4 * g4 + 1] * al + bv.y;
+                                o.z = acc[nt][mt][4 * g4 + 2] * al + bv.z;
+                                o.w = acc[nt][mt][4 * g4 + 3] * al + bv.w;
+                            }
                             const int chunk = j * 8 + 2 * g4 + lhi;
                             *(float4*)(stg + l31_p * 64 + ((chunk ^ (l31_p & 7)) << 2)) = o;
                         }
@@ -531,6 +575,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     const int idx = lane_p + it * 64;
                     const int r = idx / CPO, cj = idx % CPO;
                     const int m = mbase + r, n = ocol + cj * 8;
+                    float s1 = 0.f, s2 = 0.f;
                     if (m < p.M && n < ncols_out) {
                         const float4 a = *(const float4*)(stg + r * 64 + (((2 * cj) ^ (r & 7)) << 2));
                         const float4 b = *(const float4*)(stg + r * 64 + (((2 * cj + 1) ^ (r & 7)) << 2));
@@ -557,12 +602,43 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                                 for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
                             }
                         }
-                        *(bf16x8_raw*)(C + out_row(m) * p.ldc + n) = pack8(f);
+                        const bf16x8_raw packed = pack8(f);
+                        *(bf16x8_raw*)(C + out_row(m) * p.ldc + n) = packed;
+                        if (stats_out) {   // LayerNorm statistics of the values as STORED (bf16), for the consumer's fold
+                            float g[8];
+                            unpack8(packed, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                s1 += g[e];
+                                s2 = __builtin_fmaf(g[e], g[e], s2);
+                            }
+                        }
+                    }
+                    if (stats_out) {
+                        // the CPO lanes that share a row are neighbours: butterfly over them, lane cj == 0 adds the pass's
+                        // partial to the wave's per-row accumulators in LDS (same wave -> ordered)
+                        if constexpr (CPO >= 2) {
+                            s1 += __shfl_xor(s1, 1);
+                            s2 += __shfl_xor(s2, 1);
+                        }
+                        if constexpr (CPO >= 4) {
+                            s1 += __shfl_xor(s1, 2);
+                            s2 += __shfl_xor(s2, 2);
+                        }
+                        if constexpr (CPO >= 8) {
+                            s1 += __shfl_xor(s1, 4);
+                            s2 += __shfl_xor(s2, 4);
+                        }
+                        if (cj == 0) {
+                            atomicAdd(rowacc + 2 * r, s1);
+                            atomicAdd(rowacc + 2 * r + 1, s2);
+                        }
                     }
                 }
             };
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
+                if (FEAT == 3 && p.stats_out) rowacc[lane] = 0.f;
                 if (geglu) {
 #pragma unroll
                     for (int nt = 0; nt + 1 < TN; nt += 2) pass(std::integral_constant<int, 32>{}, mt, nt, (wcol0 >> 1) + nt * 16);
@@ -571,6 +647,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 #pragma unroll
                     for (int nt = 0; nt + 1 < TN; nt += 2) pass(std::integral_constant<int, 64>{}, mt, nt, wcol0 + nt * 32);
                     if constexpr (TN % 2 == 1) pass(std::integral_constant<int, 32>{}, mt, TN - 1, wcol0 + (TN - 1) * 32);
+                }
+                if (FEAT == 3 && p.stats_out) {
+                    // one (sum, sumsq) slot per (row, N tile, wave column): deterministic partials, no global atomics
+                    const int mrow = m0 + wm * TM * 32 + mt * 32 + (lane >> 1);
+                    if (mrow < p.M)
+                        p.stats_out[((bz * p.M + mrow) * (long long)p.stats_p + (bn * WN + wn)) * 2 + (lane & 1)] = rowacc[lane];
                 }
             }
             return;
@@ -676,35 +758,51 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST>
+template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT = 0>
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int TILES = NST * (BM + BN) * BK * 2;
-    constexpr int STG = WM * WN * 32 * 64 * 4;                    // fp32 staging slabs of the epilogue
+    constexpr int STG = WM * WN * (32 * 64 * 4 + 256);            // fp32 staging slabs of the epilogue + row-stat accumulators
     constexpr int LDS = TILES > STG ? TILES : STG;
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, BK, CONV, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS);
         attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST>), grid, dim3(WM * WN * 64), LDS, stream, a);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>), grid, dim3(WM * WN * 64), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int NST = 2>
+template <int WM, int WN, int TM, int TN, int BK, int NST = 2, bool LN_OK = false>
 int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
+    if (a.ln_side || a.stats_out) {
+        if constexpr (LN_OK) {
+            if (a.mode == 0 && a.ln_side == 1 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 1>(a, stream);
+            if (a.mode == 0 && a.ln_side == 2 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 2>(a, stream);
+            if (a.mode == 0 && a.ln_side == 0) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 3>(a, stream);
+        }
+        SDV_REQUIRE(false, "sdv_gemm_bf16: the LayerNorm fold / row statistics exist for dense GEMMs on tiles 1, 6, 7, 9 only (and not combined)");
+    }
     return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST>(a, stream)
                        : launch_igemm_t<WM, WN, TM, TN, BK, true, NST>(a, stream);
 }
 
 }  // namespace
 
-extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
+static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only);
+
+extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) { return sdv_gemm_impl(args, stream, false); }
+
+// Number of (sum, sumsq) slots per output row that sdv_gemm_bf16 would write to `stats_out` for these arguments
+// (= N tiles x wave columns of the tile the launch would pick); the caller sizes stats_out as [batch][M][slots][2] floats.
+extern "C" int sdv_gemm_stats_slots(const sdv_gemm_args* args) { return sdv_gemm_impl(args, nullptr, true); }
+
+static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only) {
     SDV_REQUIRE(args != nullptr, "sdv_gemm_bf16: null args");
     sdv_gemm_args a = *args;
     SDV_REQUIRE(a.X && a.W && a.C, "sdv_gemm_bf16: null operand");
@@ -764,6 +862,13 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     }
     if (a.bias_mode == 0 && a.bias) a.bias_mode = 1;
     if (a.alpha == 0.f) a.alpha = 1.f;
+    SDV_REQUIRE(a.ln_side >= 0 && a.ln_side <= 2, "sdv_gemm_bf16: bad ln_side %d", a.ln_side);
+    if (a.ln_side) SDV_REQUIRE(a.ln_stats && a.ln_s && !(a.ln_side == 2 && (a.epi == 1 || a.bias_mode == 1)),
+                               "sdv_gemm_bf16: ln_side needs ln_stats + ln_s (column-side: no GEGLU, per-row bias only)");
+    if (a.ln_side || a.stats_out)
+        SDV_REQUIRE((a.ldc & 7) == 0 && (a.N & 15) == 0 && (((uintptr_t)a.C | (uintptr_t)a.bias | (uintptr_t)a.ln_s | (uintptr_t)a.ln_stats) & 15) == 0 &&
+                        (!a.R || (a.ldr & 7) == 0) && ((a.sC | a.sR) & 7) == 0 && (((uintptr_t)a.R) & 15) == 0 && a.mode != 4,
+                    "sdv_gemm_bf16: the LayerNorm fold / row statistics need the aligned epilogue");
     SDV_REQUIRE(a.alpha_cols >= 0 && a.alpha_cols % 8 == 0 && (a.alpha_cols == 0 || a.epi != 1),
                 "sdv_gemm_bf16: alpha_cols=%d must be a multiple of 8 (and is not available with GEGLU)", a.alpha_cols);
     hipStream_t s = (hipStream_t)stream;
@@ -795,17 +900,24 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) {
     }
     a.tile = 4;   // the kernel reads `tile` as the raster strip width: 8 x 4 blocks of output tiles per XCD wave (1 / 2 / 4 / 8
                   // measured on the UNet: 120.2 / 118.5 / 118.1 / 118.0 ms per forward, profiles/round2_raster_order.txt)
+    {
+        static const int kBN[] = {0, 128, 64, 64, 128, 0, 320, 256, 128, 320, 32, 64, 320, 256};
+        static const int kWN[] = {0, 2, 1, 2, 2, 0, 2, 2, 2, 2, 1, 1, 2, 2};
+        SDV_REQUIRE(tile >= 1 && tile <= 13 && kBN[tile], "sdv_gemm_bf16: bad tile %d", tile);
+        a.stats_p = ((a.N + kBN[tile] - 1) / kBN[tile]) * kWN[tile];
+    }
+    if (plan_only) return a.stats_p;
     SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     switch (tile) {
 #ifndef SDV_GEMM_RING_ONLY   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
-        case 1: return launch_igemm<2, 2, 2, 2, 64>(a, s);    // 128 x 128, 4 waves
+        case 1: return launch_igemm<2, 2, 2, 2, 64, 2, true>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
         case 3: return launch_igemm<2, 2, 1, 1, 64>(a, s);    //  64 x  64
         case 4: return launch_igemm<2, 2, 4, 2, 64>(a, s);    // 256 x 128, 4 waves
-        case 6: return launch_igemm<4, 2, 2, 5, 64>(a, s);    // 256 x 320, 8 waves (UNet widths are multiples of 320)
-        case 7: return launch_igemm<4, 2, 2, 4, 64>(a, s);    // 256 x 256, 8 waves
+        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true>(a, s);    // 256 x 320, 8 waves (UNet widths are multiples of 320)
+        case 7: return launch_igemm<4, 2, 2, 4, 64, 2, true>(a, s);    // 256 x 256, 8 waves
         case 8: return launch_igemm<4, 2, 2, 2, 64>(a, s);    // 256 x 128, 8 waves
-        case 9: return launch_igemm<4, 2, 1, 5, 64>(a, s);    // 128 x 320, 8 waves
+        case 9: return launch_igemm<4, 2, 1, 5, 64, 2, true>(a, s);    // 128 x 320, 8 waves
         case 10: return launch_igemm<4, 1, 2, 1, 64>(a, s);   // 256 x  32, 4 waves (RRDB growth convs, Cout = 32)
         case 11: return launch_igemm<4, 1, 2, 2, 64>(a, s);   // 256 x  64, 4 waves
 #endif

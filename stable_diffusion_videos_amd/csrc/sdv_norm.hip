@@ -351,3 +351,32 @@ extern "C" int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const f
     SDV_CHECK_LAUNCH("sdv_layernorm_bf16");
     return SDV_OK;
 }
+
+
+// ---- LayerNorm statistics from the producer GEMM's per-row partials (LayerNorm folded into the consumer GEMM) ---------
+namespace {
+__global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ part, long long rows, int slots, float inv_c,
+                                                                float eps, float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float2* pr = (const float2*)part + r * slots;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < slots; ++i) {        // fixed order: deterministic
+        const float2 v = pr[i];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float mean = s1 * inv_c;
+    const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+    ((float2*)out)[r] = make_float2(mean, rsqrtf(var + eps));
+}
+}  // namespace
+
+extern "C" int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, int32_t C, float eps, float* out,
+                                     void* stream) {
+    SDV_REQUIRE(partials && out && rows > 0 && slots > 0 && C > 0, "sdv_rowstats_finalize: bad args");
+    hipLaunchKernelGGL(rowstats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials,
+                       (long long)rows, slots, 1.0f / C, eps, out);
+    SDV_CHECK_LAUNCH("sdv_rowstats_finalize");
+    return SDV_OK;
+}

@@ -23,7 +23,7 @@ import torch
 
 from . import hip
 from .config import UNetConfig, VAEConfig
-from .weights import StateDict, conv_w, conv_w_c4, geglu_interleave, lin_w, upconv_phase_w, vec
+from .weights import StateDict, conv_w, conv_w_c4, geglu_interleave, lin_w, ln_fold, upconv_phase_w, vec
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -88,20 +88,26 @@ class _Transformer:
         self.w_in, self.b_in = lin_w(sd[p + ".proj_in.weight"], device), vec(sd[p + ".proj_in.bias"], device)
         self.w_out, self.b_out = lin_w(sd[p + ".proj_out.weight"], device), vec(sd[p + ".proj_out.bias"], device)
         b = p + ".transformer_blocks.0"
-        self.ln = [(vec(sd[f"{b}.norm{i}.weight"], device), vec(sd[f"{b}.norm{i}.bias"], device)) for i in (1, 2, 3)]
-        self.wqk1 = lin_w(torch.cat([sd[f"{b}.attn1.to_q.weight"], sd[f"{b}.attn1.to_k.weight"]], 0), device)
-        self.wv1 = lin_w(sd[f"{b}.attn1.to_v.weight"], device)
-        self.wo1, self.bo1 = lin_w(sd[f"{b}.attn1.to_out.0.weight"], device), vec(sd[f"{b}.attn1.to_out.0.bias"], device)
-        self.wq2 = lin_w(sd[f"{b}.attn2.to_q.weight"], device)
-        self.wk2 = lin_w(sd[f"{b}.attn2.to_k.weight"], device)
-        self.wv2 = lin_w(sd[f"{b}.attn2.to_v.weight"], device)
-        self.wo2, self.bo2 = lin_w(sd[f"{b}.attn2.to_out.0.weight"], device), vec(sd[f"{b}.attn2.to_out.0.bias"], device)
-        self.wff1 = lin_w(geglu_interleave(sd[f"{b}.ff.net.0.proj.weight"]), device)
-        self.bff1 = vec(geglu_interleave(sd[f"{b}.ff.net.0.proj.bias"]), device)
-        self.wff2, self.bff2 = lin_w(sd[f"{b}.ff.net.2.weight"], device), vec(sd[f"{b}.ff.net.2.bias"], device)
         self.C = self.w_in.shape[0]
         self.heads = heads
         self.dh = self.C // heads
+        qs = hip.q_prescale(self.dh)       # softmax scale * log2(e): the alpha of every Q projection (hip.attention, q_prescaled)
+        # The three LayerNorms are folded into the GEMMs they feed (weights.ln_fold / sdv_hip.h ln_side): the GEMM that
+        # PRODUCES the normalised tensor also emits its row statistics, the consumers read the un-normalised tensor.
+        ln1, ln2, ln3 = ((sd[f"{b}.norm{i}.weight"], sd[f"{b}.norm{i}.bias"]) for i in (1, 2, 3))
+        wq, sq, tq = ln_fold(sd[f"{b}.attn1.to_q.weight"], *ln1, None, device, scale=qs)
+        wk, sk, tk = ln_fold(sd[f"{b}.attn1.to_k.weight"], *ln1, None, device)
+        self.wqk1 = torch.cat([wq, wk], 0).contiguous()               # [2C, C] = [Wq' ; Wk']
+        self.sqk1, self.tqk1 = torch.cat([sq, sk]).contiguous(), torch.cat([tq, tk]).contiguous()
+        self.wv1, self.sv1, self.tv1 = ln_fold(sd[f"{b}.attn1.to_v.weight"], *ln1, None, device)
+        self.wo1, self.bo1 = lin_w(sd[f"{b}.attn1.to_out.0.weight"], device), vec(sd[f"{b}.attn1.to_out.0.bias"], device)
+        self.wq2, self.sq2, self.tq2 = ln_fold(sd[f"{b}.attn2.to_q.weight"], *ln2, None, device, scale=qs)
+        self.wk2 = lin_w(sd[f"{b}.attn2.to_k.weight"], device)
+        self.wv2 = lin_w(sd[f"{b}.attn2.to_v.weight"], device)
+        self.wo2, self.bo2 = lin_w(sd[f"{b}.attn2.to_out.0.weight"], device), vec(sd[f"{b}.attn2.to_out.0.bias"], device)
+        self.wff1, self.sff1, self.bff1 = ln_fold(geglu_interleave(sd[f"{b}.ff.net.0.proj.weight"]), *ln3,
+                                                  geglu_interleave(sd[f"{b}.ff.net.0.proj.bias"]), device)
+        self.wff2, self.bff2 = lin_w(sd[f"{b}.ff.net.2.weight"], device), vec(sd[f"{b}.ff.net.2.bias"], device)
         self.groups = groups
         # per batch size: (K [N*Lc, C], V^T [N, C, ldv] zero padded, Lc) - persistent so captured graphs stay valid
         self.ctx: Dict[int, tuple] = {}            # the (K, V^T, Lc) the next forward of a given batch size uses
@@ -133,27 +139,25 @@ class _Transformer:
         Mb, M = nb * HW, nimg * HW
         scale = dh ** -0.5
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
-        h = hip.linear(h, self.w_in, self.b_in)
-        # --- self attention ---
-        n1 = hip.layernorm(h, *self.ln[0])
+        h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)            # + (mean, rstd) of every token for norm1
+        # --- self attention: LN1 lives inside the Q/K and V^T projections ---
         qs = hip.q_prescale(dh)       # softmax scale * log2(e), applied by the Q projections before their single rounding
-        qk = hip.linear(n1, self.wqk1, alpha=qs, alpha_cols=C)            # [Mb, 2C] = [Q * qs | K]
+        qk = hip.linear(h, self.wqk1, self.tqk1, alpha=qs, alpha_cols=C, ln=(st1, self.sqk1))   # [Mb, 2C] = [Q * qs | K]
         ldv = _round_up(HW, 64)
-        hip.gemm(self.wv1, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C,
-                 sC=C * ldv)                                              # V^T [nb][C][ldv]
+        hip.gemm(self.wv1, h, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C,
+                 sC=C * ldv, bias=self.tv1, bias_mode=2, ln=(st1, self.sv1), ln_side=2)     # V^T [nb][C][ldv]
         o = torch.empty((Mb, C), dtype=BF16, device=x.device)
         hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
                       scale=scale, k_off=C, q_prescaled=True)
-        h = hip.linear(o, self.wo1, self.bo1, residual=h)
-        # --- cross attention on the text context ---
-        n2 = hip.layernorm(h, *self.ln[1])
-        q = hip.linear(n2, self.wq2, alpha=qs)
+        h, st2 = hip.linear(o, self.wo1, self.bo1, residual=h, want_stats=True)
+        # --- cross attention on the text context (LN2 inside the Q projection) ---
+        q = hip.linear(h, self.wq2, self.tq2, alpha=qs, ln=(st2, self.sq2))
         o2 = torch.empty((M, C), dtype=BF16, device=x.device)
         ctx_k, ctx_vt, Lc = self.ctx[nimg]
         if not shared_prefix:
             hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
                           ldo=C, scale=scale, q_prescaled=True)
-            h = hip.linear(o2, self.wo2, self.bo2, residual=h)
+            h, st3 = hip.linear(o2, self.wo2, self.bo2, residual=h, want_stats=True)
         else:
             # same queries against the unconditional and the conditional context; the residual stream h is still
             # shared, so the output projection reads it with batch stride 0 and writes both halves
@@ -161,12 +165,11 @@ class _Transformer:
                 hip.attention(q, ctx_k[half * nb * Lc:], ctx_vt[half * nb:], o2[half * Mb:], B=nb, H=heads, Lq=HW, Lk=Lc,
                               dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2], ldo=C, scale=scale, q_prescaled=True)
             h2 = torch.empty((M, C), dtype=BF16, device=x.device)
-            hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
-                     sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+            st3 = hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
+                           sX=Mb * C, sW=0, sC=Mb * C, sR=0, want_stats=True)
             h = h2
-        # --- GEGLU feed-forward ---
-        n3 = hip.layernorm(h, *self.ln[2])
-        g = hip.linear(n3, self.wff1, self.bff1, epi=1)                   # [M, 4C]
+        # --- GEGLU feed-forward (LN3 inside ff.net.0) ---
+        g = hip.linear(h, self.wff1, self.bff1, epi=1, ln=(st3, self.sff1))   # [M, 4C]
         h = hip.linear(g, self.wff2, self.bff2, residual=h)
         if not shared_prefix:
             return hip.linear(h, self.w_out, self.b_out, residual=x)

@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("batch", C.c_int32), ("tile", C.c_int32), ("alpha", C.c_float),
         ("div_hw_mul", C.c_uint32), ("div_hw_shr", C.c_uint32), ("div_w_mul", C.c_uint32), ("div_w_shr", C.c_uint32),
         ("alpha_cols", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
     ]
 
 
@@ -46,6 +47,8 @@ _SIGNATURES = {
     "sdv_last_error": (C.c_char_p, []),
     "sdv_abi_version": (C.c_int, []),
     "sdv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "sdv_gemm_stats_slots": (C.c_int, [C.POINTER(GemmArgs)]),
+    "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
@@ -159,8 +162,12 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          epi: int = 0, mode: int = 0, Hin: int = 0, Win: int = 0, Hout: int = 0, Wout: int = 0,
          circular: bool = False, batch: int = 1, sX: int = 0, sW: int = 0, sC: int = 0, sR: int = 0,
          step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
-         x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0):
-    """Raw wrapper of ``sdv_gemm_bf16`` (element offsets x_off / w_off / out_off select sub-matrices)."""
+         x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None, ln_side: int = 1,
+         want_stats: bool = False, ln_eps: float = 1e-5):
+    """Raw wrapper of ``sdv_gemm_bf16`` (element offsets x_off / w_off / out_off select sub-matrices).
+    ``ln=(stats, s)``: LayerNorm folded into this GEMM (sdv_hip.h): ``stats`` fp32 [rows, 2] = (mean, rstd) from
+    ``want_stats`` of the producer, ``s`` fp32 row sums of the gamma-scaled weights.  ``want_stats=True`` returns the
+    (mean, rstd) [batch*M, 2] of this GEMM's OUTPUT rows over its N columns (for the next LayerNorm)."""
     lib = load()
     a = GemmArgs()
     a.X = _ptr(x, BF16, "X") + 2 * x_off
@@ -177,6 +184,15 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, Hin, Win, Hout, Wout, int(circular)
     a.epi, a.bias_mode, a.bias_step_stride = epi, (bias_mode if bias is not None else 0), bias_step_stride
     a.batch, a.tile, a.alpha, a.alpha_cols = batch, tile, alpha, alpha_cols
+    if ln is not None:
+        a.ln_stats, a.ln_s, a.ln_side = _ptr(ln[0], F32, "ln_stats"), _ptr(ln[1], F32, "ln_s"), ln_side
+    partials = None
+    if want_stats:
+        slots = lib.sdv_gemm_stats_slots(C.byref(a))
+        if slots <= 0:
+            _check(-1, "sdv_gemm_stats_slots")
+        partials = torch.empty((max(batch, 1) * M, slots, 2), dtype=F32, device=x.device)
+        a.stats_out = partials.data_ptr()
     taps = 1 if mode == 0 else 9
     # algorithmic work: the phase form (mode 4) is a nearest-2x upsample + conv3x3 on 4*M output pixels (9 taps each);
     # it EXECUTES 4 taps per output pixel
@@ -184,11 +200,21 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     _launch("gemm" if mode == 0 else "conv3x3",
             dict(M=M * (4 if mode == 4 else 1), N=N, K=K * taps, batch=batch, flops=flops, mode=mode, epi=epi),
             lambda: _check(lib.sdv_gemm_bf16(C.byref(a), _stream()), "sdv_gemm_bf16"))
+    if want_stats:
+        nout = N // 2 if epi == 1 else N
+        stats = torch.empty((max(batch, 1) * M, 2), dtype=F32, device=x.device)
+        _launch("ln_stats", dict(bytes=8.0 * partials.shape[0] * (partials.shape[1] + 1)),
+                lambda: _check(lib.sdv_rowstats_finalize(partials.data_ptr(), partials.shape[0], partials.shape[1], nout, ln_eps,
+                                                         stats.data_ptr(), _stream()), "sdv_rowstats_finalize"))
+        return stats
+    return None
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, residual=None, out=None,
-           epi: int = 0, x2: Optional[torch.Tensor] = None, alpha: float = 1.0, tile: int = 0, alpha_cols: int = 0) -> torch.Tensor:
-    """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias) (+ residual); x2 = optional second K-source (concat)."""
+           epi: int = 0, x2: Optional[torch.Tensor] = None, alpha: float = 1.0, tile: int = 0, alpha_cols: int = 0, ln=None,
+           want_stats: bool = False, ln_eps: float = 1e-5):
+    """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias) (+ residual); x2 = optional second K-source (concat).
+    ``ln`` / ``want_stats``: see ``gemm`` (with want_stats the return value is ``(y, stats)``)."""
     M, K1 = x.shape
     K2 = x2.shape[1] if x2 is not None else 0
     N, K = w.shape
@@ -199,10 +225,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         tile = _GEGLU_TILE                       # experiment knob (SDV_GEGLU_TILE)
     if out is None:
         out = torch.empty((M, n_out), dtype=BF16, device=x.device)
-    gemm(x, w, out, M=M, N=N, K=K, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
-         residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2, C1=K1 if x2 is not None else 0,
-         ldx2=x2.stride(0) if x2 is not None else 0, alpha=alpha, epi=epi, tile=tile, alpha_cols=alpha_cols)
-    return out
+    st = gemm(x, w, out, M=M, N=N, K=K, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
+              residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2, C1=K1 if x2 is not None else 0,
+              ldx2=x2.stride(0) if x2 is not None else 0, alpha=alpha, epi=epi, tile=tile, alpha_cols=alpha_cols, ln=ln,
+              want_stats=want_stats, ln_eps=ln_eps)
+    return (out, st) if want_stats else out
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, nimg: int, H: int, W: int,

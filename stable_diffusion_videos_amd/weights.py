@@ -339,6 +339,25 @@ def vec(v: torch.Tensor, device) -> torch.Tensor:
     return v.contiguous().to(device=device, dtype=torch.float32)
 
 
+def ln_fold(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor], device, scale: float = 1.0):
+    """Fold a LayerNorm (gamma, beta) that FEEDS the linear layer y = LN(x) W^T + b into the layer (sdv_hip.h ``ln_side``):
+
+        W' = bf16(gamma o W)            the weights the GEMM multiplies the UN-normalised x with
+        s  = rowsum(W')                  (of the rounded W', so that a constant row x = c 1 cancels exactly: x W'^T - mean s = 0)
+        t  = scale * (W beta + b)        what the GEMM adds as its bias; ``scale`` = the GEMM's alpha on these rows (pre-scaled Q)
+
+    so that LN(x) W^T + b = rstd (x W'^T - mean s) + t.  Returns (W' bf16 [N, K], s fp32 [N], t fp32 [N]) on ``device``."""
+    wf = w.reshape(w.shape[0], -1).to(device=device, dtype=torch.float32)
+    g = gamma.to(device=device, dtype=torch.float32)
+    b = beta.to(device=device, dtype=torch.float32)
+    wp = (wf * g[None, :]).to(torch.bfloat16)
+    s = wp.to(torch.float32).sum(dim=1).contiguous()
+    t = (wf * b[None, :]).sum(dim=1)
+    if bias is not None:
+        t = t + bias.to(device=device, dtype=torch.float32)
+    return wp.contiguous(), s, (t * scale).contiguous()
+
+
 def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
     """ff.net.0.proj rows are [value(4C) | gate(4C)]; the GEGLU epilogue wants every 32-row MFMA tile to hold
     [16 value rows | the 16 gate rows of the same channels], so that value and gate of a channel meet in the same

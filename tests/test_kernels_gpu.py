@@ -109,6 +109,53 @@ def test_gemm_geglu(hip, dev, tile):
     assert rel_l2(out.float(), ref) < MFMA_TOL
 
 
+@pytest.mark.parametrize("tile", [0, 1, 6, 7, 9])
+@pytest.mark.parametrize("M,C,N2", [(512, 320, 640), (300, 640, 1280), (4096, 320, 2560)])
+def test_gemm_layernorm_fold(hip, dev, tile, M, C, N2):
+    """LayerNorm folded into the GEMMs around it (BasicTransformerBlock.norm1/2/3, reached from unet(...) at
+    stable_diffusion_pipeline.py:418): the producer GEMM emits (mean, rstd) of the rows it stores, the consumers multiply the
+    UN-normalised rows with gamma-scaled weights - against F.layer_norm + F.linear in fp32.  Row-side (to_q / to_k / ff),
+    GEGLU, column-side (the transposed V^T projection, batched) and a large row mean (|mean| = 8 sigma)."""
+    from stable_diffusion_videos_amd.weights import geglu_interleave, ln_fold
+    x, w0 = rnd((M, C), dev, 110), rnd((C, C), dev, 111, C ** -0.5)
+    b0, res = rnd((C,), dev, 112), rnd((M, C), dev, 113)
+    res[:, :] += 8.0                                              # a residual stream with a large common mode
+    res = bf16_round(res)
+    gamma, beta = 1.0 + 0.3 * rnd((C,), dev, 114), 0.2 * rnd((C,), dev, 115)
+    # producer: y = x W0^T + b0 + res, plus the statistics of the bf16 rows it wrote
+    y, st = hip.linear(x.to(BF16), w0.to(BF16), b0, residual=res.to(BF16), want_stats=True, tile=tile)
+    yf = y.float()
+    mean, var = yf.mean(1), yf.var(1, unbiased=False)
+    assert torch.allclose(st[:, 0], mean, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(st[:, 1], torch.rsqrt(var + 1e-5), rtol=2e-3)
+    ln = F.layer_norm(yf, (C,), gamma, beta, 1e-5)
+    # consumer, row-side, with an alpha on the leading columns (pre-scaled Q)
+    w1, b1 = rnd((N2, C), dev, 116, C ** -0.5), rnd((N2,), dev, 117)
+    qs = 0.23
+    wq, sq, tq = ln_fold(w1[: N2 // 2], gamma, beta, b1[: N2 // 2], dev, scale=qs)
+    wk, sk, tk = ln_fold(w1[N2 // 2:], gamma, beta, b1[N2 // 2:], dev)
+    out = hip.linear(y, torch.cat([wq, wk]), torch.cat([tq, tk]), alpha=qs, alpha_cols=N2 // 2, ln=(st, torch.cat([sq, sk])),
+                     tile=tile)
+    ref = ln @ w1.T + b1
+    ref[:, : N2 // 2] *= qs
+    assert rel_l2(out.float(), ref) < MFMA_TOL
+    # GEGLU consumer
+    wg, sg, tg = ln_fold(geglu_interleave(w1), gamma, beta, geglu_interleave(b1), dev)
+    out = hip.linear(y, wg, tg, epi=1, ln=(st, sg), tile=tile)
+    full = ln @ w1.T + b1
+    assert rel_l2(out.float(), full[:, : N2 // 2] * F.gelu(full[:, N2 // 2:])) < MFMA_TOL
+    # column-side: V^T[b] = Wv LN(y[b])^T, two samples of M/2 tokens each
+    if M % 128 == 0:
+        wv = rnd((C, C), dev, 118, C ** -0.5)
+        wvp, sv, tv = ln_fold(wv, gamma, beta, None, dev)
+        L = M // 2
+        vt = torch.zeros((2, C, L), dtype=BF16, device=dev)
+        hip.gemm(wvp, y, vt, M=C, N=L, K=C, ldx=C, ldw=C, ldc=L, batch=2, sX=0, sW=L * C, sC=C * L, bias=tv, bias_mode=2,
+                 ln=(st, sv), ln_side=2, tile=tile)
+        ref = torch.einsum("ck,blk->bcl", wv, ln.view(2, L, C))
+        assert rel_l2(vt.float(), ref) < MFMA_TOL
+
+
 def test_gemm_batched_transposed_output(hip, dev):
     """The V^T projection: per-sample [C, L] = Wv [C, K] . X[b] [L, K]^T with a padded leading dim."""
     B, L, Cc, K, ld = 3, 77, 128, 64, 128
