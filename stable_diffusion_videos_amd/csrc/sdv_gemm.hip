@@ -458,7 +458,46 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         if (aligned) {
             float* stg = (float*)smem + wave * (32 * 64);
             float* rowacc = (float*)smem + NWV * (32 * 64) + wave * 64;   // (sum, sumsq) of this wave's 32 rows (stats_out)
+            // Per-column epilogue vectors of this tile's BN columns, staged in LDS ONCE per tile: bias, the LayerNorm-fold row
+            // sums s (ln_side 1) or the per-column (mean, rstd) (ln_side 2).  Reading them per accumulator quad straight from
+            // global memory cost 3.7 us per 256 x 320 tile per vector (20 dependent 16-byte loads per m-tile and lane):
+            // "+bias" alone was +16 % on the K = 320 projections (profiles/round1_gemm_overhead.txt).
+            float* vbias = (float*)smem + NWV * (32 * 64 + 64);
+            float* vaux = vbias + BN;            // [BN] (ln_side 1) or [BN][2] (ln_side 2)
+            // per-ROW LayerNorm-fold operands of this lane's TM rows, fetched once (before the barrier: their latency hides
+            // behind it): ln_side 1 -> (mean, rstd) of the row, ln_side 2 -> s of the row
+            float ln_row[TM][2];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                ln_row[mt][0] = 0.f;
+                ln_row[mt][1] = 1.f;
+                const int mrow = m0 + wm * TM * 32 + mt * 32 + l31;
+                if constexpr (FEAT == 1) {
+                    if (mrow < p.M) {
+                        const float2 st = *(const float2*)(p.ln_stats + 2 * (bz * p.M + mrow));
+                        ln_row[mt][0] = st.x;
+                        ln_row[mt][1] = st.y;
+                    }
+                } else if constexpr (FEAT == 2) {
+                    if (mrow < p.M) ln_row[mt][0] = p.ln_s[mrow];
+                }
+            }
             __syncthreads();  // every wave has left the K loop: the tile buffers may be overwritten
+            {
+                constexpr int lnsd = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
+                const bool col_bias = bias && p.bias_mode == 1;
+                for (int i = tid; i < BN; i += NWV * 64) {
+                    const int n = n0 + i;
+                    vbias[i] = (col_bias && n < p.N) ? bias[n] : 0.f;
+                    if constexpr (lnsd == 1) vaux[i] = n < p.N ? p.ln_s[n] : 0.f;
+                    if constexpr (lnsd == 2) {
+                        float2 st = make_float2(0.f, 1.f);
+                        if (n < p.N) st = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
+                        *(float2*)(vaux + 2 * i) = st;
+                    }
+                }
+            }
+            __syncthreads();
             // one pass: n-tiles [nt0, nt0+ntc) of m-tile mt -> OC output columns starting at ocol
             auto pass = [&](auto oc_tag, int mt, int nt0, int ocol) {
                 constexpr int OC = decltype(oc_tag)::value;   // 64 / 32 / 16 output columns
@@ -486,16 +525,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 //   LN(x) W^T = rstd * (x (gamma o W)^T - mean * s) + (W beta + b),  s = row sums of gamma o W
                 // side 1: (mean, rstd) belong to the output ROW (this lane's m), s to the output column;
                 // side 2 (the transposed V^T projection): (mean, rstd) belong to the output COLUMN, s to the row.
-                float ln_mu = 0.f, ln_rs = 1.f, ln_sm = 0.f;
                 constexpr int ln_side = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
                 float* const stats_out = FEAT == 3 ? p.stats_out : nullptr;
-                if (ln_side == 1 && mrow < p.M) {
-                    const float2 st = *(const float2*)(p.ln_stats + 2 * (bz * p.M + mrow));
-                    ln_mu = st.x;
-                    ln_rs = st.y;
-                } else if (ln_side == 2 && mrow < p.M) {
-                    ln_sm = p.ln_s[mrow];
-                }
+                const float ln_mu = ln_row[mt][0], ln_rs = ln_row[mt][1], ln_sm = ln_row[mt][0];
                 if (geglu) {
                     // W rows are interleaved [16 value | 16 gate] per 32-row MFMA tile: accumulator quads g and g+2 of
                     // a lane hold the value and the gate of the SAME 4 channels -> 16 output columns per n-tile
@@ -505,15 +537,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         for (int g = 0; g < 2; ++g) {
                             const int nt = nt0 + j;
                             const int nv = wcol0 + nt * 32 + 8 * g + 4 * lhi;
-                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
-                            if (bias && nv + 19 < p.N) {
-                                bv = *(const float4*)(bias + nv);
-                                bg = *(const float4*)(bias + nv + 16);
-                            }
+                            const float4 bv = *(const float4*)(vbias + (nv - n0));
+                            const float4 bg = *(const float4*)(vbias + (nv - n0) + 16);
                             float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = sv;
-                            if (ln_side == 1 && nv + 19 < p.N) {
-                                sv = *(const float4*)(p.ln_s + nv);
-                                sg = *(const float4*)(p.ln_s + nv + 16);
+                            if constexpr (ln_side == 1) {
+                                sv = *(const float4*)(vaux + (nv - n0));
+                                sg = *(const float4*)(vaux + (nv - n0) + 16);
                             }
                             const float ar = alpha * ln_rs;
                             float4 o;
@@ -531,31 +560,23 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         for (int g4 = 0; g4 < 4; ++g4) {
                             const int nt = nt0 + j;
                             const int nb = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;
-                            float4 bv = make_float4(bm_, bm_, bm_, bm_);
-                            if (bias && p.bias_mode == 1 && nb + 3 < p.N) {
-                                const float4 t4 = *(const float4*)(bias + nb);
-                                bv.x += t4.x;
-                                bv.y += t4.y;
-                                bv.z += t4.z;
-                                bv.w += t4.w;
-                            }
+                            float4 bv = *(const float4*)(vbias + (nb - n0));
+                            bv.x += bm_;
+                            bv.y += bm_;
+                            bv.z += bm_;
+                            bv.w += bm_;
                             float4 o;
                             const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
-                            if (ln_side == 1) {
-                                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (nb + 3 < p.N) s4 = *(const float4*)(p.ln_s + nb);
+                            if constexpr (ln_side == 1) {
+                                const float4 s4 = *(const float4*)(vaux + (nb - n0));
                                 const float ar = al * ln_rs;
                                 o.x = (acc[nt][mt][4 * g4 + 0] - ln_mu * s4.x) * ar + bv.x;
                                 o.y = (acc[nt][mt][4 * g4 + 1] - ln_mu * s4.y) * ar + bv.y;
                                 o.z = (acc[nt][mt][4 * g4 + 2] - ln_mu * s4.z) * ar + bv.z;
                                 o.w = (acc[nt][mt][4 * g4 + 3] - ln_mu * s4.w) * ar + bv.w;
-                            } else if (ln_side == 2) {
-                                float4 st0 = make_float4(0.f, 1.f, 0.f, 1.f), st1 = st0;   // (mean, rstd) of columns nb .. nb+3
-                                if (nb + 3 < p.N) {
-                                    const float* st = p.ln_stats + 2 * (bz * p.N + nb);
-                                    st0 = *(const float4*)(st);
-                                    st1 = *(const float4*)(st + 4);
-                                }
+                            } else if constexpr (ln_side == 2) {
+                                const float4 st0 = *(const float4*)(vaux + 2 * (nb - n0));       // (mean, rstd) of columns nb, nb+1
+                                const float4 st1 = *(const float4*)(vaux + 2 * (nb - n0) + 4);   //                 nb+2, nb+3
                                 o.x = (acc[nt][mt][4 * g4 + 0] - st0.x * ln_sm) * (st0.y * al) + bv.x;
                                 o.y = (acc[nt][mt][4 * g4 + 1] - st0.z * ln_sm) * (st0.w * al) + bv.y;
                                 o.z = (acc[nt][mt][4 * g4 + 2] - st1.x * ln_sm) * (st1.y * al) + bv.z;
@@ -762,7 +783,7 @@ template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT =
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int TILES = NST * (BM + BN) * BK * 2;
-    constexpr int STG = WM * WN * (32 * 64 * 4 + 256);            // fp32 staging slabs of the epilogue + row-stat accumulators
+    constexpr int STG = WM * WN * (32 * 64 * 4 + 256) + 3 * BN * 4;   // fp32 staging slabs of the epilogue + row-stat accumulators + column vectors
     constexpr int LDS = TILES > STG ? TILES : STG;
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
@@ -866,7 +887,7 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     if (a.ln_side) SDV_REQUIRE(a.ln_stats && a.ln_s && !(a.ln_side == 2 && (a.epi == 1 || a.bias_mode == 1)),
                                "sdv_gemm_bf16: ln_side needs ln_stats + ln_s (column-side: no GEGLU, per-row bias only)");
     if (a.ln_side || a.stats_out)
-        SDV_REQUIRE((a.ldc & 7) == 0 && (a.N & 15) == 0 && (((uintptr_t)a.C | (uintptr_t)a.bias | (uintptr_t)a.ln_s | (uintptr_t)a.ln_stats) & 15) == 0 &&
+        SDV_REQUIRE((a.ldc & 7) == 0 && ((a.epi == 1 ? a.N >> 1 : a.N) & 7) == 0 && (((uintptr_t)a.C | (uintptr_t)a.bias | (uintptr_t)a.ln_s | (uintptr_t)a.ln_stats) & 15) == 0 &&
                         (!a.R || (a.ldr & 7) == 0) && ((a.sC | a.sR) & 7) == 0 && (((uintptr_t)a.R) & 15) == 0 && a.mode != 4,
                     "sdv_gemm_bf16: the LayerNorm fold / row statistics need the aligned epilogue");
     SDV_REQUIRE(a.alpha_cols >= 0 && a.alpha_cols % 8 == 0 && (a.alpha_cols == 0 || a.epi != 1),
@@ -890,6 +911,7 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         double best = 1e300;
         for (const Cand& c : cands) {
             if (a.epi >= 3 && c.id >= 6) continue;   // extended activations exist in the 4-wave tiles only
+            if ((a.ln_side || a.stats_out) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9)) continue;   // LN fold tiles
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
             const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {

@@ -17,6 +17,7 @@ What is hoisted out of the 50-step loop (the reference recomputes all of it ever
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -100,6 +101,10 @@ class _Transformer:
         self.wqk1 = torch.cat([wq, wk], 0).contiguous()               # [2C, C] = [Wq' ; Wk']
         self.sqk1, self.tqk1 = torch.cat([sq, sk]).contiguous(), torch.cat([tq, tk]).contiguous()
         self.wv1, self.sv1, self.tv1 = ln_fold(sd[f"{b}.attn1.to_v.weight"], *ln1, None, device)
+        # token counts that are not a multiple of 8 (2 x 2 latents of the small test configurations) cannot use the aligned
+        # epilogue of the transposed V^T projection: those run norm1 as a kernel of its own
+        self.ln1_plain = (vec(ln1[0], device), vec(ln1[1], device))
+        self.wv1_plain = lin_w(sd[f"{b}.attn1.to_v.weight"], device)
         self.wo1, self.bo1 = lin_w(sd[f"{b}.attn1.to_out.0.weight"], device), vec(sd[f"{b}.attn1.to_out.0.bias"], device)
         self.wq2, self.sq2, self.tq2 = ln_fold(sd[f"{b}.attn2.to_q.weight"], *ln2, None, device, scale=qs)
         self.wk2 = lin_w(sd[f"{b}.attn2.to_k.weight"], device)
@@ -109,6 +114,14 @@ class _Transformer:
                                                   geglu_interleave(sd[f"{b}.ff.net.0.proj.bias"]), device)
         self.wff2, self.bff2 = lin_w(sd[f"{b}.ff.net.2.weight"], device), vec(sd[f"{b}.ff.net.2.bias"], device)
         self.groups = groups
+        # A/B switch (tools/unet_ab.py): SDV_LN_FOLD=0 keeps the three LayerNorms as kernels of their own
+        self.fold = os.environ.get("SDV_LN_FOLD", "1") != "0"
+        if not self.fold:
+            self.ln_plain = [(vec(sd[f"{b}.norm{i}.weight"], device), vec(sd[f"{b}.norm{i}.bias"], device)) for i in (1, 2, 3)]
+            self.p_wqk1 = lin_w(torch.cat([sd[f"{b}.attn1.to_q.weight"], sd[f"{b}.attn1.to_k.weight"]], 0), device)
+            self.p_wq2 = lin_w(sd[f"{b}.attn2.to_q.weight"], device)
+            self.p_wff1 = lin_w(geglu_interleave(sd[f"{b}.ff.net.0.proj.weight"]), device)
+            self.p_bff1 = vec(geglu_interleave(sd[f"{b}.ff.net.0.proj.bias"]), device)
         # per batch size: (K [N*Lc, C], V^T [N, C, ldv] zero padded, Lc) - persistent so captured graphs stay valid
         self.ctx: Dict[int, tuple] = {}            # the (K, V^T, Lc) the next forward of a given batch size uses
         self.ctx_by_len: Dict[tuple, tuple] = {}
@@ -138,14 +151,20 @@ class _Transformer:
         nb = nimg // 2 if shared_prefix else nimg          # samples in the context-free prefix
         Mb, M = nb * HW, nimg * HW
         scale = dh ** -0.5
+        if not self.fold:
+            return self._call_unfolded(x, nimg, H, W, vt_ws, shared_prefix)
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
         h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)            # + (mean, rstd) of every token for norm1
         # --- self attention: LN1 lives inside the Q/K and V^T projections ---
         qs = hip.q_prescale(dh)       # softmax scale * log2(e), applied by the Q projections before their single rounding
         qk = hip.linear(h, self.wqk1, self.tqk1, alpha=qs, alpha_cols=C, ln=(st1, self.sqk1))   # [Mb, 2C] = [Q * qs | K]
         ldv = _round_up(HW, 64)
-        hip.gemm(self.wv1, h, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C,
-                 sC=C * ldv, bias=self.tv1, bias_mode=2, ln=(st1, self.sv1), ln_side=2)     # V^T [nb][C][ldv]
+        if HW % 8 == 0:
+            hip.gemm(self.wv1, h, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C,
+                     sC=C * ldv, bias=self.tv1, bias_mode=2, ln=(st1, self.sv1), ln_side=2)     # V^T [nb][C][ldv]
+        else:
+            n1 = hip.layernorm(h, *self.ln1_plain)
+            hip.gemm(self.wv1_plain, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C, sC=C * ldv)
         o = torch.empty((Mb, C), dtype=BF16, device=x.device)
         hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
                       scale=scale, k_off=C, q_prescaled=True)
@@ -174,6 +193,49 @@ class _Transformer:
         if not shared_prefix:
             return hip.linear(h, self.w_out, self.b_out, residual=x)
         out = torch.empty((M, C), dtype=BF16, device=x.device)           # residual x is the shared (nb-sample) input
+        hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
+                 sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+        return out
+
+
+    def _call_unfolded(self, x, nimg, H, W, vt_ws, shared_prefix):
+        """The same block with the three LayerNorms as stand-alone kernels (A/B reference for the fold, SDV_LN_FOLD=0)."""
+        C, HW, heads, dh = self.C, H * W, self.heads, self.dh
+        nb = nimg // 2 if shared_prefix else nimg
+        Mb, M = nb * HW, nimg * HW
+        scale, qs = dh ** -0.5, hip.q_prescale(dh)
+        h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
+        h = hip.linear(h, self.w_in, self.b_in)
+        n1 = hip.layernorm(h, *self.ln_plain[0])
+        qk = hip.linear(n1, self.p_wqk1, alpha=qs, alpha_cols=C)
+        ldv = _round_up(HW, 64)
+        hip.gemm(self.wv1_plain, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C, sC=C * ldv)
+        o = torch.empty((Mb, C), dtype=BF16, device=x.device)
+        hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
+                      scale=scale, k_off=C, q_prescaled=True)
+        h = hip.linear(o, self.wo1, self.bo1, residual=h)
+        n2 = hip.layernorm(h, *self.ln_plain[1])
+        q = hip.linear(n2, self.p_wq2, alpha=qs)
+        o2 = torch.empty((M, C), dtype=BF16, device=x.device)
+        ctx_k, ctx_vt, Lc = self.ctx[nimg]
+        if not shared_prefix:
+            hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
+                          ldo=C, scale=scale, q_prescaled=True)
+            h = hip.linear(o2, self.wo2, self.bo2, residual=h)
+        else:
+            for half in range(2):
+                hip.attention(q, ctx_k[half * nb * Lc:], ctx_vt[half * nb:], o2[half * Mb:], B=nb, H=heads, Lq=HW, Lk=Lc,
+                              dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2], ldo=C, scale=scale, q_prescaled=True)
+            h2 = torch.empty((M, C), dtype=BF16, device=x.device)
+            hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
+                     sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+            h = h2
+        n3 = hip.layernorm(h, *self.ln_plain[2])
+        g = hip.linear(n3, self.p_wff1, self.p_bff1, epi=1)
+        h = hip.linear(g, self.wff2, self.bff2, residual=h)
+        if not shared_prefix:
+            return hip.linear(h, self.w_out, self.b_out, residual=x)
+        out = torch.empty((M, C), dtype=BF16, device=x.device)
         hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
                  sX=Mb * C, sW=0, sC=Mb * C, sR=0)
         return out

@@ -188,6 +188,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
         a.ln_stats, a.ln_s, a.ln_side = _ptr(ln[0], F32, "ln_stats"), _ptr(ln[1], F32, "ln_s"), ln_side
     partials = None
     if want_stats:
+        a.stats_out = 16          # (non-null while planning: the tile choice depends on it)
         slots = lib.sdv_gemm_stats_slots(C.byref(a))
         if slots <= 0:
             _check(-1, "sdv_gemm_stats_slots")
