@@ -322,6 +322,40 @@ CONFIG1_MIN = {"embeds_db": 50.5, "lat1_db": 54.0, "lat10_db": 49.0, "lat25_db":
                "frames_mean_abs": 1.5}
 
 
+def test_sd21_768_two_steps_with_audio_schedule(hip, dev):
+    """BASELINE config 4 geometry (examples/make_music_video.py:43-55 call shape): SD-2.1 architecture at 768x768 (96x96
+    latent, 9216-token self-attention with 64-wide heads, v-prediction, 1024-d text context), two interpolated frames whose
+    T comes from the audio (get_timesteps_arr on the reference's tests/samples/choice.wav), 2 DDIM steps, CFG 7.5 - against
+    the CPU oracle (about a minute of oracle time)."""
+    from oracle import interp
+    from oracle.pipeline import denoise_and_decode, numpy_to_uint8
+    from oracle.scheduler import DDIMScheduler as OracleDDIM
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline, get_timesteps_arr
+    pipe = StableDiffusionWalkPipeline.from_pretrained("stabilityai/stable-diffusion-2-1", arch="sd21")
+    assert pipe.scheduler.config.prediction_type == "v_prediction"
+    o_unet, o_vae = _oracle_for((pipe.unet, pipe.vae))
+    pipe.to(dev)
+    wav = Path(__file__).parent / "samples" / "choice.wav"
+    T = get_timesteps_arr(str(wav), offset=2.0, duration=1.0, fps=2, margin=1.0, smooth=0.0)          # 2 audio-driven positions
+    assert T.shape == (2,) and 0.0 <= T[0] <= T[1] <= 1.0
+    batches = list(pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, 96, 96), T, 2))
+    _, emb, lat = batches[0]
+    ea, eb = pipe.embed_text("a cat").cpu(), pipe.embed_text("a dog").cpu()
+    ref_in = list(interp.generate_inputs(ea, eb, interp.init_noise(42, (1, 4, 96, 96)), interp.init_noise(1337, (1, 4, 96, 96)), T, 2))[0]
+    assert float((emb.cpu() - ref_in[1]).abs().max()) < 1e-5 and float((lat.cpu() - ref_in[2]).abs().max()) < 2e-5
+    uncond = pipe.embed_text("").cpu()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = denoise_and_decode(o_unet, o_vae, OracleDDIM(prediction_type="v_prediction"), ref_in[1], uncond, ref_in[2],
+                             num_inference_steps=2, guidance_scale=7.5)
+    out = pipe(latents=lat, text_embeddings=emb, height=768, width=768, num_inference_steps=2, guidance_scale=7.5,
+               output_type="numpy")["images"]
+    p = psnr(torch.from_numpy(out), torch.from_numpy(ref), peak=1.0)
+    d8 = np.abs((out * 255).round().astype(int) - numpy_to_uint8(ref).astype(int))
+    report(f"SD-2.1 768x768 (config 4), audio T {T.round(3).tolist()}, 2 steps, CFG: frame PSNR {p:.1f} dB, uint8 max-abs {d8.max()} "
+           f"mean-abs {d8.mean():.3f}")
+    assert out.shape == (2, 768, 768, 3) and p >= 38.0
+
+
 def test_pipeline_variants(hip, dev):
     """eta > 0 (DDIM variance noise), negative prompt, num_images_per_prompt, prompt= entry, v-prediction."""
     from oracle.pipeline import denoise_and_decode
