@@ -143,6 +143,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
             sh[e] = beta[c] - gmean[ge] * a;
         }
         int p = p_begin + tp;
+        // 4 independent 16-byte loads in flight per thread before the first use (as in the statistics pass)
+        for (; p + 3 * g.PT < p_end; p += 4 * g.PT) {
+            bf16x8_raw r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                r[u] = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, (long long)img * HW + p + u * g.PT, c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8(r[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = f[e] * sc[e] + sh[e];
+                    f[e] = silu ? silu_f(v) : v;
+                }
+                *(bf16x8_raw*)(Y + ((long long)img * HW + p + u * g.PT) * C + c0) = pack8(f);
+            }
+        }
         for (; p < p_end; p += g.PT) {
             const long long pix = (long long)img * HW + p;
             const bf16x8_raw r = *(const bf16x8_raw*)gn_src(X, X2, C1, C2, pix, c0);
@@ -312,8 +330,12 @@ extern "C" int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_
     const int C = C1 + C2;
     SDV_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C > 0, "sdv_groupnorm_apply: channels must be multiples of 8");
     SDV_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "sdv_groupnorm_apply: bad groups");
-    // ~32 KB of activation per block keeps > 2k blocks in flight on the big tensors
-    int ppb = (16384 + C - 1) / C;
+    // Elements per block: ~4k blocks in total, between 16 K and 128 K elements each.  Measured at 128 samples
+    // (tools/gn_bench.py): 64^2 x 320 channels 3.4 TB/s with 16 K-element blocks (10 k blocks) vs 5.0 TB/s with 64 K; the
+    // 32^2 / 16^2 levels are best at 16 K - 32 K.
+    long long ppb_elems = (long long)nimg * HW * C / 4096;
+    ppb_elems = ppb_elems < 16384 ? 16384 : (ppb_elems > 131072 ? 131072 : ppb_elems);
+    int ppb = (int)((ppb_elems + C - 1) / C);
     if (ppb < 1) ppb = 1;
     const int nblk = (HW + ppb - 1) / ppb;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nimg), dim3(256), 0, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,

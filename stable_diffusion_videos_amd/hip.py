@@ -306,7 +306,11 @@ def softmax_rows_(s: torch.Tensor, rows: int, cols: int, ld: int):
 
 
 def gn_splits(HW: int) -> int:
-    return max(1, min(64, HW // 64))
+    """Pixel ranges the statistics pass cuts an image into.  The apply pass re-reduces the partials in every block, so it
+    wants few of them, the statistics pass wants enough blocks to fill the chip: 256 pixels per split at the 64 x 64 level
+    and above, 128 at 32 x 32, 64 below (tools/gn_bench.py at 128 samples: apply 152 -> 114 us on 64^2 x 320 channels)."""
+    pix = 256 if HW >= 4096 else (128 if HW >= 1024 else 64)
+    return max(1, min(64, HW // pix))
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg: int, HW: int, groups: int,
