@@ -155,11 +155,12 @@ def kernel_pass(pipe, embeds, noise, size, steps):
     return out
 
 
-def pmc_profile():
+def pmc_profile(batch):
     """Counters of the committed rocprofv3 --pmc passes over one UNet forward at this bench's batch
-    (profiles/round2_pmc_unet_b64.csv, made by tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950).  Returns {kernel substring: {counter: mean per launch}} or {} when the file is not there."""
-    path = ROOT / "profiles" / "round2_pmc_unet_b64.csv"
+    (profiles/round2_pmc_unet_b<batch>.csv, made by tools/pmc_summary.py from `rocprofv3 --pmc ... tools/unet_once.py <batch>`;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns {kernel: {counter: mean per launch}} or {}
+    when there is no profile for this batch size."""
+    path = ROOT / "profiles" / f"round2_pmc_unet_b{batch}.csv"
     if not path.exists():
         return {}
     import csv
@@ -180,7 +181,7 @@ def dominant_kernel_traffic(pmc):
     for k, c in pmc.items():
         if k.startswith("igemm_kernel<4, 2, 2, 5, 64, true") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return {"kernel": k, "fetch_bytes": round(c["FETCH_SIZE"] * 2 * 1024), "write_bytes": round(c["WRITE_SIZE"] * 1024),
-                    "source": "profiles/round2_pmc_unet_b64.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                    "source": "profiles/round2_pmc_unet_b<batch>.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
     return None
 
 
@@ -200,7 +201,7 @@ def attention_object(shapes, pmc):
         if k.startswith("attention_kernel<40, 2") and "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             # busy cycles summed over 1024 SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs
             out["mfma_busy_pmc"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
-            out["mfma_busy_source"] = "profiles/round2_pmc_unet_b64.csv"
+            out["mfma_busy_source"] = "profiles/round2_pmc_unet_b<batch>.csv"
     return out
 
 
@@ -344,7 +345,7 @@ def main():
             kp = kernel_pass(pipe, embeds, noise, size, args.inference_steps)
             shapes = kp.pop("_unet_shapes")
             result["roofline"]["kernels"] = kp
-            pmc = pmc_profile() if (args.arch == "sd14" and size == 512) else {}
+            pmc = pmc_profile(B) if (args.arch == "sd14" and size == 512) else {}
             # dominant kernel = the implicit-GEMM conv (largest share of GPU time): algorithmic TFLOP/s live (HIP events),
             # HBM-side traffic per launch from the committed PMC passes of the same forward
             dom = kp.get("unet.conv3x3")
