@@ -96,6 +96,12 @@ typedef struct sdv_gemm_args {
     float* stats_out;
     int32_t ln_side;
     int32_t stats_p;      /* filled in by sdv_gemm_bf16 */
+    /* fp8 != 0: X (X2) and W hold OCP e4m3 bytes instead of bf16 (ldx / ldw / C1 / K still count ELEMENTS; rows must be 16-byte
+     * multiples).  v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate, bf16 output; pass the product of the two per-tensor
+     * dequantisation scales as `alpha`.  BASELINE.json configs[4] ("SD-v1-4 fp8"): the reference has no fp8 line of its own
+     * (its dtype is whatever torch_dtype says, stable_diffusion_pipeline.py:840-858); here the ResBlock convolutions take fp8
+     * activations written by sdv_groupnorm_apply(Y8, q_scale) and fp8 weights.  Tiles 1 / 6 / 7 / 9. */
+    int32_t fp8;
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
@@ -138,6 +144,11 @@ int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32
                         int32_t HW, int32_t groups, int32_t splits, const float* partials,
                         const float* gamma, const float* beta, float eps, int32_t silu, sdv_bf16* Y,
                         void* stream);
+/* as sdv_groupnorm_apply, writing OCP e4m3 bytes Y8 = sat(y * q_scale) (the fp8 conv's activation operand) */
+int sdv_groupnorm_apply_fp8(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
+                            int32_t HW, int32_t groups, int32_t splits, const float* partials,
+                            const float* gamma, const float* beta, float eps, int32_t silu, uint8_t* Y8,
+                            float q_scale, void* stream);
 
 /* LayerNorm over the last dim of [rows][C] bf16 (BasicTransformerBlock.norm1/2/3) */
 int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta, float eps, int64_t rows,

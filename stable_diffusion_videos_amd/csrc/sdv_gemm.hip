@@ -46,8 +46,11 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     constexpr bool XACT = NWV == 4;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int ROWB = BK * 2;            // bytes per LDS row (128 or 64)
-    constexpr int CPRW = BK / 8;            // 16-byte chunks per row (8 or 4)
+    // FEAT 8: fp8 (OCP e4m3) operands - X and W are bytes, the MFMA is v_mfma_f32_32x32x16_fp8_fp8 (bf16 rate, half the
+    // LDS-DMA and LDS-read bytes per MFMA), accumulation fp32, output bf16; the per-tensor dequantisation scale is `alpha`.
+    constexpr int ES = FEAT == 8 ? 1 : 2;   // operand element size in bytes
+    constexpr int ROWB = BK * ES;           // bytes per LDS row (128 or 64)
+    constexpr int CPRW = ROWB / 16;         // 16-byte chunks per row (8 or 4)
     constexpr int RPI = 1024 / ROWB;        // rows one wave-instruction (1 KiB) moves (8 or 16)
     constexpr int TILE_BYTES = (BM + BN) * ROWB;
     constexpr int GX = BM / RPI, GW = BN / RPI;                    // 1-KiB row groups of the X / W panels
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     constexpr int KSTEPS = BK / 16;
     static_assert(BM % RPI == 0 && BN % RPI == 0, "panels must be whole 1-KiB groups");
     static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(FEAT != 8 || (BK == 64 && NST == 2), "fp8 tiles: 64 elements (64 bytes) per K tile, double buffered");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     constexpr int kRecords = 0x7ffffff0;
     const int rg = lane / CPRW;   // row inside the group one wave-instruction moves
     const int pc = lane % CPRW;   // physical 16-B chunk inside the LDS row
-    auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    auto swz = [](int r) { return ROWB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
     long long xbase1, xbase2;     // element offsets of the window start in X / X2 (wave-uniform)
     int pix0 = 0;
     if constexpr (CONV) {
@@ -110,10 +114,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         xbase1 = bz * p.sX + (long long)m0 * p.ldx;
         xbase2 = (long long)m0 * p.ldx2;
     }
-    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + xbase1), 0, kRecords, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X2 + xbase2), 0, kRecords, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + bz * p.sW + (long long)n0 * p.ldw), 0, kRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + xbase1 * ES), 0, kRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X2 + xbase2 * ES), 0, kRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.W + (bz * p.sW + (long long)n0 * p.ldw) * ES), 0, kRecords, 0x00020000);
 
     int xr_[NX];               // dense: row inside the tile (or -1 beyond M); conv: pixel index of the image origin - pix0
     int xay[NX], xax[NX];      // conv: anchor coordinates (oy*stride, ox*stride) or (oy, ox) for upsample
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int rw = (wave + NWV * i) * RPI + rg;  // row inside the W panel
-        wvo[i] = (n0 + rw < p.N) ? (unsigned)(rw * p.ldw * 2 + (pc ^ swz(BM + rw)) * 16) : kOOB;
+        wvo[i] = (n0 + rw < p.N) ? (unsigned)(rw * p.ldw * ES + (pc ^ swz(BM + rw)) * 16) : kOOB;
     }
 
     // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     const int ext_x = p.mode == 3 ? p.Wout : p.Win;
 
     auto new_segment = [&]() {
-        const int ld2 = 2 * (srcsel ? p.ldx2 : p.ldx);
+        const int ld2 = ES * (srcsel ? p.ldx2 : p.ldx);
         if constexpr (CONV) {
             // mode 4 (one phase (py, px) = blockIdx.z of a nearest-2x-upsample + conv3x3, see sdv_hip.h): 2 x 2 taps on the
             // low-resolution grid, rows {y-1+py, y+py}, columns {x-1+px, x+px}
@@ -245,6 +251,32 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     constexpr bool kPipeFrags = TM * TN >= 8;   // big tiles: 1 workgroup / CU, hide LDS latency inside the wave
     auto compute = [&](int buf) {
         const char* base = smem + buf * TILE_BYTES;
+        if constexpr (ES == 1) {
+            // fp8: a K tile is 64 bytes per row = four 16-byte chunks.  One ds_read_b128 of chunk 2j + lhi yields two
+            // 8-byte MFMA operands, used for k-steps 2j and 2j+1 (both operands walk K in the same permuted order, so the
+            // contraction is unchanged): 2 fragment reads per row set and K tile feed 4 k-steps.
+            typedef __attribute__((ext_vector_type(2))) long long i64x2_t;
+            i64x2_t xq[2][TM], wq[2][TN];
+            auto load_q = [&](int j, i64x2_t* xd, i64x2_t* wd) {
+                const int lc = j * 2 + lhi;
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const i64x2_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const i64x2_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+            };
+            load_q(0, xq[0], wq[0]);
+            load_q(1, xq[1], wq[1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wq[j][nt][h], xq[j][mt][h], acc[nt][mt], 0, 0, 0);
+            return;
+        }
         if constexpr (!kPipeFrags) {
             // small wave tiles run 2+ workgroups per CU: other waves cover the LDS latency, registers matter more
 #pragma unroll
@@ -782,7 +814,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT = 0>
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int TILES = NST * (BM + BN) * BK * 2;
+    constexpr int TILES = NST * (BM + BN) * BK * (FEAT == 8 ? 1 : 2);
     constexpr int STG = WM * WN * (32 * 64 * 4 + 256) + 3 * BN * 4;   // fp32 staging slabs of the epilogue + row-stat accumulators + column vectors
     constexpr int LDS = TILES > STG ? TILES : STG;
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
@@ -801,6 +833,14 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
 
 template <int WM, int WN, int TM, int TN, int BK, int NST = 2, bool LN_OK = false>
 int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
+    if (a.fp8) {
+        if constexpr (LN_OK) {   // the same four 8-wave / 4-wave tiles carry the fp8 variants
+            SDV_REQUIRE(!a.ln_side && !a.stats_out, "sdv_gemm_bf16: fp8 operands do not combine with the LayerNorm fold");
+            return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 8>(a, stream)
+                               : launch_igemm_t<WM, WN, TM, TN, BK, true, NST, 8>(a, stream);
+        }
+        SDV_REQUIRE(false, "sdv_gemm_bf16: fp8 operands exist on tiles 1, 6, 7, 9 only");
+    }
     if (a.ln_side || a.stats_out) {
         if constexpr (LN_OK) {
             if (a.mode == 0 && a.ln_side == 1 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 1>(a, stream);
@@ -838,6 +878,8 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     }
     SDV_REQUIRE(a.C1 % 64 == 0 && a.C1 > 0 && a.C1 <= a.K, "sdv_gemm_bf16: C1=%d must be a multiple of 64 in (0,K]", a.C1);
     SDV_REQUIRE(a.ldx % 8 == 0 && a.ldx2 % 8 == 0 && a.ldw % 8 == 0, "sdv_gemm_bf16: ldx/ldx2/ldw must be multiples of 8");
+    SDV_REQUIRE(a.fp8 == 0 || a.fp8 == 1, "sdv_gemm_bf16: bad fp8 flag %d", a.fp8);
+    if (a.fp8) SDV_REQUIRE(a.ldx % 16 == 0 && a.ldx2 % 16 == 0 && a.ldw % 16 == 0, "sdv_gemm_bf16: fp8 rows must be 16-byte multiples");
     if (a.mode != 0) {
         SDV_REQUIRE(a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "sdv_gemm_bf16: bad conv geometry");
         SDV_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "sdv_gemm_bf16: M must be nimg*Hout*Wout");
@@ -911,7 +953,7 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         double best = 1e300;
         for (const Cand& c : cands) {
             if (a.epi >= 3 && c.id >= 6) continue;   // extended activations exist in the 4-wave tiles only
-            if ((a.ln_side || a.stats_out) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9)) continue;   // LN fold tiles
+            if ((a.ln_side || a.stats_out || a.fp8) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9)) continue;   // LN fold / fp8 tiles
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
             const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {

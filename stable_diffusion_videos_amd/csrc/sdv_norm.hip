@@ -100,12 +100,33 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
     }
 }
 
+// 8 floats -> 8 OCP e4m3 bytes, saturating at +-448 (v_cvt_pk_fp8_f32 rounds to nearest even)
+__device__ __forceinline__ uint2 pack8_fp8(const float* f, float q) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(f[e] * q, -448.f), 448.f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+// FP8OUT: Y is bytes (e4m3) = sat(y * q_scale) instead of bf16 - the activation operand of the fp8 conv
+template <bool FP8OUT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ X2,
                                                        int C1, int C2, int HW, int groups, int splits,
                                                        const float* __restrict__ partials,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, int silu, int pix_per_block,
-                                                       uint16_t* __restrict__ Y) {
+                                                       uint16_t* __restrict__ Y, float q_scale) {
+    auto put = [&](long long pix, int c0, const float* f) {
+        if constexpr (FP8OUT)
+            *(uint2*)((uint8_t*)Y + pix * C1 + pix * C2 + c0) = pack8_fp8(f, q_scale);
+        else
+            *(bf16x8_raw*)(Y + pix * (C1 + C2) + c0) = pack8(f);
+    };
     __shared__ float gmean[64], grstd[64];
     const int C = C1 + C2;
     const GnGeom g = gn_geom(C);
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
                     float v = f[e] * sc[e] + sh[e];
                     f[e] = silu ? silu_f(v) : v;
                 }
-                *(bf16x8_raw*)(Y + ((long long)img * HW + p + u * g.PT) * C + c0) = pack8(f);
+                put((long long)img * HW + p + u * g.PT, c0, f);
             }
         }
         for (; p < p_end; p += g.PT) {
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
                 float v = f[e] * sc[e] + sh[e];
                 f[e] = silu ? silu_f(v) : v;
             }
-            *(bf16x8_raw*)(Y + pix * C + c0) = pack8(f);
+            put(pix, c0, f);
         }
     }
 }
@@ -321,10 +342,9 @@ extern "C" int sdv_groupnorm_stats(const sdv_bf16* X, const sdv_bf16* X2, int32_
     return SDV_OK;
 }
 
-extern "C" int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
-                                   int32_t HW, int32_t groups, int32_t splits, const float* partials,
-                                   const float* gamma, const float* beta, float eps, int32_t silu, sdv_bf16* Y,
-                                   void* stream) {
+static int gn_apply_launch(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg, int32_t HW,
+                           int32_t groups, int32_t splits, const float* partials, const float* gamma, const float* beta,
+                           float eps, int32_t silu, void* Y, bool fp8, float q_scale, void* stream) {
     SDV_REQUIRE(X && partials && gamma && beta && Y, "sdv_groupnorm_apply: null pointer");
     SDV_REQUIRE(C2 == 0 || X2, "sdv_groupnorm_apply: C2 > 0 needs X2");
     const int C = C1 + C2;
@@ -338,10 +358,27 @@ extern "C" int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_
     int ppb = (int)((ppb_elems + C - 1) / C);
     if (ppb < 1) ppb = 1;
     const int nblk = (HW + ppb - 1) / ppb;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nimg), dim3(256), 0, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,
-                       groups, splits, partials, gamma, beta, eps, silu, ppb, Y);
+    if (fp8)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nblk, nimg), dim3(256), 0, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,
+                           groups, splits, partials, gamma, beta, eps, silu, ppb, (uint16_t*)Y, q_scale);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nblk, nimg), dim3(256), 0, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,
+                           groups, splits, partials, gamma, beta, eps, silu, ppb, (uint16_t*)Y, 1.0f);
     SDV_CHECK_LAUNCH("sdv_groupnorm_apply");
     return SDV_OK;
+}
+
+extern "C" int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg, int32_t HW,
+                                   int32_t groups, int32_t splits, const float* partials, const float* gamma,
+                                   const float* beta, float eps, int32_t silu, sdv_bf16* Y, void* stream) {
+    return gn_apply_launch(X, X2, C1, C2, nimg, HW, groups, splits, partials, gamma, beta, eps, silu, Y, false, 1.0f, stream);
+}
+
+extern "C" int sdv_groupnorm_apply_fp8(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg, int32_t HW,
+                                       int32_t groups, int32_t splits, const float* partials, const float* gamma,
+                                       const float* beta, float eps, int32_t silu, uint8_t* Y8, float q_scale, void* stream) {
+    SDV_REQUIRE(q_scale > 0.f, "sdv_groupnorm_apply_fp8: q_scale must be positive");
+    return gn_apply_launch(X, X2, C1, C2, nimg, HW, groups, splits, partials, gamma, beta, eps, silu, Y8, true, q_scale, stream);
 }
 
 extern "C" int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta, float eps, int64_t rows,

@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("div_hw_mul", C.c_uint32), ("div_hw_shr", C.c_uint32), ("div_w_mul", C.c_uint32), ("div_w_shr", C.c_uint32),
         ("alpha_cols", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
+        ("fp8", C.c_int32),
     ]
 
 
@@ -54,6 +55,8 @@ _SIGNATURES = {
     "sdv_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
                             [C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdv_groupnorm_apply_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
+                                [C.c_float, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]),
     "sdv_layernorm_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sdv_conv3x3_cin_small": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
     "sdv_im2col3x3_c4": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
@@ -130,6 +133,8 @@ def _ptr(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+FP8 = torch.float8_e4m3fn      # OCP e4m3, what gfx950's fp8 MFMA and converters use
+FP8_MAX = 448.0
 
 _zero_pages = {}
 _GEGLU_TILE = int(__import__("os").environ.get("SDV_GEGLU_TILE", "0"))
@@ -170,9 +175,16 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     (mean, rstd) [batch*M, 2] of this GEMM's OUTPUT rows over its N columns (for the next LayerNorm)."""
     lib = load()
     a = GemmArgs()
-    a.X = _ptr(x, BF16, "X") + 2 * x_off
-    a.X2 = _ptr(x2, BF16, "X2")
-    a.W = _ptr(w, BF16, "W") + 2 * w_off
+    fp8 = x.dtype == FP8
+    if fp8:
+        if w.dtype != FP8 or (x2 is not None and x2.dtype != FP8) or x_off or w_off:
+            raise SdvHipError("gemm: fp8 activations need fp8 weights (and no operand offsets)")
+        a.fp8 = 1
+        a.X, a.X2, a.W = _ptr(x, FP8, "X"), _ptr(x2, FP8, "X2"), _ptr(w, FP8, "W")
+    else:
+        a.X = _ptr(x, BF16, "X") + 2 * x_off
+        a.X2 = _ptr(x2, BF16, "X2")
+        a.W = _ptr(w, BF16, "W") + 2 * w_off
     a.bias = _ptr(bias, F32, "bias")
     a.R = _ptr(residual, BF16, "R")
     a.C = _ptr(out, BF16, "C") + 2 * out_off
@@ -314,23 +326,29 @@ def gn_splits(HW: int) -> int:
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg: int, HW: int, groups: int,
-              eps: float, silu: bool, x2: Optional[torch.Tensor] = None, out=None) -> torch.Tensor:
-    """GroupNorm(+SiLU) over NHWC [nimg*HW, C1] (++ [.., C2] concatenated on channels) -> bf16 [.., C1+C2]."""
+              eps: float, silu: bool, x2: Optional[torch.Tensor] = None, out=None, fp8_scale: Optional[float] = None) -> torch.Tensor:
+    """GroupNorm(+SiLU) over NHWC [nimg*HW, C1] (++ [.., C2] concatenated on channels) -> bf16 [.., C1+C2].
+    ``fp8_scale`` s: the result is written as OCP e4m3 bytes q = sat(y / s) instead (y ~ q * s), the fp8 conv's operand."""
     lib = load()
     C1 = x.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     splits = gn_splits(HW)
     partials = torch.empty((nimg, splits, groups, 2), dtype=F32, device=x.device)
     if out is None:
-        out = torch.empty((nimg * HW, C1 + C2), dtype=BF16, device=x.device)
+        out = torch.empty((nimg * HW, C1 + C2), dtype=BF16 if fp8_scale is None else FP8, device=x.device)
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise SdvHipError("groupnorm: inputs must be contiguous")
     nbytes = 2.0 * nimg * HW * (C1 + C2)
-    xp, x2p, pp, op = _ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), _ptr(partials), _ptr(out, BF16, "Y")
+    xp, x2p, pp, op = _ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), _ptr(partials), _ptr(out, BF16 if fp8_scale is None else FP8, "Y")
     gp, bp = _ptr(gamma, F32, "gamma"), _ptr(beta, F32, "beta")
     _launch("gn_stats", dict(bytes=nbytes),
             lambda: _check(lib.sdv_groupnorm_stats(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, _stream()),
                            "sdv_groupnorm_stats"))
+    if fp8_scale is not None:
+        _launch("gn_apply", dict(bytes=1.5 * nbytes),
+                lambda: _check(lib.sdv_groupnorm_apply_fp8(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, gp, bp, eps, int(silu),
+                                                           op, 1.0 / fp8_scale, _stream()), "sdv_groupnorm_apply_fp8"))
+        return out
     _launch("gn_apply", dict(bytes=2 * nbytes),
             lambda: _check(lib.sdv_groupnorm_apply(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, gp, bp, eps, int(silu),
                                                    op, _stream()), "sdv_groupnorm_apply"))

@@ -675,3 +675,59 @@ def test_torch_custom_ops_run_the_same_kernels(hip, dev):
     assert torch.allclose(torch.ops.sdv.lerp_batch(a, bb, T), torch.stack([torch.lerp(a[0], bb[0], float(t)) for t in T]), atol=1e-6)
     s3 = torch.ops.sdv.slerp_batch(a, bb, T)
     assert s3.shape == (3, 77, 64) and torch.equal(s3[0], a[0]) and torch.equal(s3[2], bb[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) operands - BASELINE config 5
+# ------------------------------------------------------------------------------------------------
+def _q8(t, amax=None):
+    """per-tensor e4m3 quantisation as the engine does it: scale = amax / 448, q = fp8(t / scale)."""
+    s = float(t.abs().max() if amax is None else amax) / 448.0
+    return (t / s).to(torch.float8_e4m3fn), s
+
+
+@pytest.mark.parametrize("tile", [0, 1, 6, 7, 9])
+def test_gemm_and_conv_fp8_operands(hip, dev, tile):
+    """sdv_gemm_bf16 with fp8 = 1 (v_mfma_f32_32x32x16_fp8_fp8): against fp32 arithmetic on the SAME quantised values -
+    what remains is fp32 accumulation order and the bf16 output rounding, i.e. the bf16 kernels' own tolerance."""
+    M, N, K = 777, 640, 1280
+    x, w = rnd((M, K), dev, 120), rnd((N, K), dev, 121, K ** -0.5)
+    bias, res = rnd((N,), dev, 122), rnd((M, N), dev, 123)
+    x8, sx = _q8(x)
+    w8, sw = _q8(w)
+    out = hip.linear(x8, w8, bias, residual=res.to(BF16), alpha=sx * sw, tile=tile)
+    ref = (x8.float() * sx) @ (w8.float() * sw).T + bias + res
+    assert rel_l2(out.float(), ref) < MFMA_TOL
+    # how far fp8 is from the bf16 arithmetic on this data (reported, not gated: ~2^-4 relative per element / sqrt(K))
+    full = x @ w.T + bias + res
+    from conftest import report
+    if tile == 0:
+        report(f"fp8 GEMM vs unquantised fp32: rel-L2 {rel_l2(out.float(), full):.2e}")
+    # conv3x3 (two-source concat, residual), NHWC
+    n, H, W, C1, C2, Cout = 2, 16, 16, 128, 64, 320
+    xa, xb = rnd((n, H, W, C1), dev, 124), rnd((n, H, W, C2), dev, 125)
+    wc = rnd((Cout, C1 + C2, 3, 3), dev, 126, (9 * (C1 + C2)) ** -0.5)
+    bc, rc = rnd((Cout,), dev, 127), rnd((n, H, W, Cout), dev, 128)
+    amax = max(float(xa.abs().max()), float(xb.abs().max()))
+    xa8, sa = _q8(xa, amax)
+    xb8, _ = _q8(xb, amax)
+    wc8, swc = _q8(wc)
+    w_ohwi = wc8.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    out = hip.conv3x3(xa8.reshape(-1, C1), w_ohwi, bc, nimg=n, H=H, W=W, x2=xb8.reshape(-1, C2), residual=rc.reshape(-1, Cout).to(BF16),
+                      alpha=sa * swc, tile=tile)
+    ref = conv_ref(torch.cat([xa8.float(), xb8.float()], -1) * sa, wc8.float() * swc, bc, 1, False) + rc
+    assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL
+
+
+def test_groupnorm_fp8_output(hip, dev):
+    """sdv_groupnorm_apply_fp8: the e4m3 bytes are the round-to-nearest quantisation of the bf16 kernel's fp32 result."""
+    n, HW, C = 2, 256, 320
+    x = rnd((n * HW, C), dev, 130)
+    g, b = 1.0 + 0.2 * rnd((C,), dev, 131), 0.1 * rnd((C,), dev, 132)
+    y = F.silu(F.group_norm(x.view(n, HW, C).transpose(1, 2), 32, g, b, 1e-5)).transpose(1, 2).reshape(n * HW, C)
+    s = float(y.abs().max()) / 448.0
+    q = hip.groupnorm(x.to(BF16), g, b, nimg=n, HW=HW, groups=32, eps=1e-5, silu=True, fp8_scale=s)
+    assert q.dtype == torch.float8_e4m3fn and q.shape == (n * HW, C)
+    d = (q.float() * s - y).abs()
+    ulp = torch.exp2(torch.floor(torch.log2((y.abs() / s).clamp_min(2.0 ** -6))) - 3) * s      # e4m3: 3 mantissa bits
+    assert float((d / ulp).max()) <= 0.75      # half an ulp + the fp32 differences of the two evaluations of y
