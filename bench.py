@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json configs[] index + 1: 2 = weak-scaled K x B frames per rank (default, the driver's "
                          "contract); 3 = the literal 8-GPU config: 4 prompts, 240 frames in total, STRONG-scaled over the ranks")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8 = BASELINE config 5: e4m3 operands in the UNet's ResBlock convs (everything else bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-walk-pass", action="store_true", help="skip the 60-frame walk() pass (frames/s including PNG files)")
     ap.add_argument("--no-kernel-pass", action="store_true")
@@ -250,7 +252,7 @@ def main():
 
     pipe = StableDiffusionWalkPipeline.from_pretrained({"sd14": "CompVis/stable-diffusion-v1-4",
                                                         "sd21": "stabilityai/stable-diffusion-2-1", "tiny": "tiny"}[args.arch],
-                                                       arch=args.arch)
+                                                       arch=args.arch, fp8=args.dtype == "fp8")
     cfgs_for_cpu = (pipe.unet.config, pipe.vae.config)
     pipe.to(dev)                                           # weight relayout (+ RCCL broadcast when world > 1)
 
@@ -327,7 +329,7 @@ def main():
         args.inference_steps == 50 else f"interpolated frames/sec ({size}x{size}, {args.inference_steps} DDIM steps)",
         "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / max(steps_done, 1), 2), "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random-init SD weights, hash-tokenised prompts)",
+        "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "fp8 (e4m3 ResBlock convs) + bf16", "data": "synthetic (seeded random-init SD weights, hash-tokenised prompts)",
         "config": {"workload": workload, "batch_size": B, "frames": frames, "parallelism": f"frame-sharded dp{world}",
                    "hipgraph": pipe.use_graphs, "baseline_config": args.config},
     }

@@ -102,14 +102,16 @@ class StableDiffusionWalkPipeline:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, *args, tiled: bool = False, torch_dtype=None,
                         revision=None, safety_checker=None, feature_extractor=None, vae=None, scheduler=None,
-                        device=None, arch: Optional[str] = None, synthetic_seed: int = 0, **kwargs):
+                        device=None, arch: Optional[str] = None, synthetic_seed: int = 0, fp8: bool = False, **kwargs):
         """Build the pipeline (reference :840-858).
 
         ``pretrained_model_name_or_path`` may be a LOCAL diffusers-layout directory (``unet/``, ``vae/``,
         ``text_encoder/``, ``tokenizer/``); there is no network, so hub ids resolve to ``$SDV_MODEL_DIR`` when
         that is set and otherwise to the same ARCHITECTURE with seeded synthetic weights (``arch`` in
         {"sd14", "sd21", "tiny"}; inferred from the name).  ``tiled=True`` makes every convolution circular
-        (the reference monkey-patches nn.Conv2d; here it is a kernel flag)."""
+        (the reference monkey-patches nn.Conv2d; here it is a kernel flag).  ``fp8=True`` (or
+        ``torch_dtype="fp8"``): the UNet's ResBlock convolutions run on the fp8 (e4m3) MFMA path with per-tensor scales
+        calibrated on the first forward; everything else stays bf16 (BASELINE.json configs[4])."""
         name = str(pretrained_model_name_or_path or "")
         model_dir = None
         if name and Path(name).is_dir():
@@ -130,7 +132,7 @@ class StableDiffusionWalkPipeline:
         if model_dir is None:
             logger.warning("from_pretrained(%r): building the %s architecture with seeded SYNTHETIC weights and the hash "
                            "tokenizer (no checkpoint on disk) - outputs are for benchmarking / parity only", name, arch)
-        if torch_dtype not in (None, torch.bfloat16, torch.float16, torch.float32):
+        if torch_dtype not in (None, torch.bfloat16, torch.float16, torch.float32, "fp8"):
             raise ValueError(f"unsupported torch_dtype {torch_dtype}")
         if model_dir is not None:
             ucfg = cfgs.unet_from_json(model_dir / "unet" / "config.json")
@@ -162,8 +164,9 @@ class StableDiffusionWalkPipeline:
                    unet=_PendingModule("unet", ucfg, u_sd), scheduler=scheduler, safety_checker=safety_checker,
                    feature_extractor=feature_extractor, requires_safety_checker=False, text_config=tcfg)
         pipe.tiled = tiled
+        pipe.fp8 = bool(fp8) or torch_dtype == "fp8"    # BASELINE config 5: e4m3 operands in the UNet's ResBlock convs
         pipe.synthetic = model_dir is None
-        pipe.torch_dtype = torch_dtype or torch.bfloat16
+        pipe.torch_dtype = torch.bfloat16 if torch_dtype in (None, "fp8") else torch_dtype
         if device is not None:
             pipe.to(device)
         return pipe
@@ -186,7 +189,7 @@ class StableDiffusionWalkPipeline:
             u, v = self.unet, self.vae
             u_shapes = weights.unet_shapes(u.config)
             u_sd = parallel.broadcast_state_dict(u.state_dict, u_shapes, device)
-            self.unet = UNetEngine(u.config, u_sd, device, tiled=self.tiled)
+            self.unet = UNetEngine(u.config, u_sd, device, tiled=self.tiled, fp8=getattr(self, "fp8", False))
             del u_sd
             u.state_dict = None
             if isinstance(v, _PendingModule):

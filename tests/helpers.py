@@ -42,10 +42,10 @@ def make_oracle_vae(c: cfgs.VAEConfig, sd):
     return _materialise(om.AutoencoderKLDecoder, oracle_vae_cfg(c), sd)
 
 
-def unet_pair(c: cfgs.UNetConfig, device, seed=0, tiled=False):
+def unet_pair(c: cfgs.UNetConfig, device, seed=0, tiled=False, fp8=False):
     from stable_diffusion_videos_amd.engine import UNetEngine
     sd = weights.synthetic_state_dict(weights.unet_shapes(c), seed=seed)
-    return make_oracle_unet(c, sd), UNetEngine(c, sd, device, tiled=tiled)
+    return make_oracle_unet(c, sd), UNetEngine(c, sd, device, tiled=tiled, fp8=fp8)
 
 
 def vae_pair(c: cfgs.VAEConfig, device, seed=1, tiled=False):

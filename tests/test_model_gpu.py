@@ -91,6 +91,26 @@ def test_sd21_unet_forward_small_latent(hip, dev):
     assert p >= 46.5
 
 
+def test_sd14_unet_forward_fp8_convs(hip, dev):
+    """BASELINE config 5 ("SD-v1-4 fp8 (CDNA4 fp8 MFMA)"): the SD-v1-4 UNet with e4m3 operands in its 44 ResBlock convolutions
+    (per-tensor scales, calibrated on the first forward) against the fp32 oracle AND against the bf16 HIP path on the same
+    inputs - the parity ladder of the fp8 mode, stated in dB."""
+    from stable_diffusion_videos_amd import config as cfgs
+    c = cfgs.sd14_unet()
+    oracle, eng8 = unet_pair(c, dev, fp8=True)
+    _, eng16 = unet_pair(c, dev)
+    x, ctx = _unet_io(c, 2, 16, 16, 77, 1)
+    got8 = _run_unet(eng8, x, ctx, [981, 961], 0, dev)       # first call calibrates the activation scales
+    got8b = _run_unet(eng8, x, ctx, [981, 961], 0, dev)
+    got16 = _run_unet(eng16, x, ctx, [981, 961], 0, dev)
+    with torch.no_grad():
+        ref = oracle(x, torch.tensor(981), ctx)
+    assert torch.equal(got8, got8b)
+    p8, p16, p816 = psnr(got8, ref), psnr(got16, ref), psnr(got8, got16, peak=float(ref.abs().max()))
+    report(f"SD-1.4 unet, fp8 ResBlock convs: eps PSNR {p8:.1f} dB vs oracle (bf16 path {p16:.1f} dB), {p816:.1f} dB vs the bf16 path")
+    assert p8 >= 27.0
+
+
 @pytest.mark.parametrize("arch", ["tiny", "sd"])
 def test_vae_decode(hip, dev, arch):
     from oracle.pipeline import decode_latents, numpy_to_uint8
