@@ -108,7 +108,7 @@ def test_sd14_unet_forward_fp8_convs(hip, dev):
     assert torch.equal(got8, got8b)
     p8, p16, p816 = psnr(got8, ref), psnr(got16, ref), psnr(got8, got16, peak=float(ref.abs().max()))
     report(f"SD-1.4 unet, fp8 ResBlock convs: eps PSNR {p8:.1f} dB vs oracle (bf16 path {p16:.1f} dB), {p816:.1f} dB vs the bf16 path")
-    assert p8 >= 27.0
+    assert p8 >= 33.5          # measured 36.7 dB (the bf16 path: 49.6 dB)
 
 
 @pytest.mark.parametrize("arch", ["tiny", "sd"])
