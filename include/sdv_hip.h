@@ -106,6 +106,11 @@ typedef struct sdv_gemm_args {
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
 int sdv_gemm_stats_slots(const sdv_gemm_args* args);
+
+/* The 8-wave tiles (6-9) run as PERSISTENT workgroups - one per CU, each walking tiles b, b + grid, ... with the next tile's
+ * first K slab prefetched behind the current tile's epilogue.  sdv_gemm_set_persistent(0) falls back to one workgroup per
+ * tile (bit-identical results; for A/B timing in tools/).  Returns the previous setting. */
+int sdv_gemm_set_persistent(int on);
 /* partial (sum, sumsq) [rows][slots][2] -> (mean, rstd) [rows][2] over C channels */
 int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, int32_t C, float eps, float* out, void* stream);
 

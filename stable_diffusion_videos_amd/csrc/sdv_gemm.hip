@@ -68,96 +68,127 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     const int wm = wave / WN;
     const int wn = wave % WN;
 
-    // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs; remap
-    // (bijectively) so that each XCD - each private L2 - works on one contiguous run of tiles: neighbouring
-    // M tiles of a conv share their halo rows, and all tiles of a run share the same W panel.
-    const int nblk = gridDim.x;
-    const int xq = nblk >> 3, xr = nblk & 7;
-    const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
-    const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    // ---- tile walk ------------------------------------------------------------------------------------------------
+    // The 8-wave double-buffered tiles (one workgroup per CU) are PERSISTENT: the host launches min(tiles, CUs) workgroups and
+    // workgroup b walks tiles b, b + grid, b + 2 grid, ...  A tile's first K slab is fetched (LDS-DMA) during the LAST K slab
+    // of the tile before it and stays in flight across that tile's epilogue, and the epilogue's stores drain behind the next
+    // tile's first MFMAs: with one workgroup per CU nothing else can cover those two latencies (they were 8-9 us of a 19 us
+    // K = 320 tile, profiles/round2_gemm_overhead.txt), and the CUs stop moving through load / compute / store phases in
+    // lockstep.  Every other tile runs this loop exactly once (grid = tiles).
+    constexpr bool PERSIST = NWV == 8 && NST == 2;
+    // LDS: [slot 0][slot 1] K-slab buffers of SLOT bytes, then the epilogue's small vectors.  The fp32 staging slabs of the
+    // epilogue alias the slot the tile's LAST K slab was read from; the other slot already receives the next tile.
+    constexpr int SLABS = NWV * 32 * 64 * 4;
+    constexpr int SLOT = PERSIST ? (TILE_BYTES > SLABS ? TILE_BYTES : SLABS) : TILE_BYTES;
     const int tiles_m = (p.M + BM - 1) / BM;
-    // Raster order inside an XCD's run: N is cut into strips of `gn` tiles and a strip is walked N-fastest, so the ~32
-    // workgroups an XCD runs at a time form a (32/gn) x gn block of output tiles - they stream 32/gn activation panels and
-    // gn weight panels through the XCD's 4 MiB L2 instead of 32 + 1 (M-fastest).  Measured with rocprofv3 FETCH_SIZE: the
-    // M-fastest order re-fetched every activation panel once per N tile from the fabric (profiles/round2_*).
-    const int tiles_n = nblk / tiles_m;
-    const int gn = p.tile > 0 ? (p.tile < tiles_n ? p.tile : tiles_n) : 1;
-    const int strip_sz = tiles_m * gn;
-    const int full = tiles_n / gn;
-    int strip = tile_id / strip_sz;
-    int gcols = gn;
-    if (strip >= full) {
-        strip = full;
-        gcols = tiles_n - full * gn;
-    }
-    const int rr = tile_id - strip * strip_sz;
-    const int bm = rr / gcols;
-    const int bn = strip * gn + (rr - bm * gcols);
-    const int m0 = bm * BM;
-    const int n0 = bn * BN;
-    const long long bz = blockIdx.z;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = tiles_m * tiles_n;
+    const int total = nblk * (p.batch > 0 ? p.batch : 1);
     const int K = p.K;
 
     // ---- operand addressing: buffer descriptors + 32-bit lane offsets + scalar K offset -----------------
     constexpr unsigned kOOB = 0x80000000u;
     constexpr int kRecords = 0x7ffffff0;
-    const int rg = lane / CPRW;   // row inside the group one wave-instruction moves
-    const int pc = lane % CPRW;   // physical 16-B chunk inside the LDS row
+    // Everything derived from the lane id is re-derived per tile from an opaque copy (lane_setup): the persistent walk must
+    // not keep ~30 addressing registers alive across the epilogue, where the 160 accumulators + the staging state already
+    // fill the 256-VGPR budget (they spilled 100-300 B of scratch per lane when simply hoisted out of the tile loop).
+    int rg, pc;    // row inside the group one wave-instruction moves / physical 16-B chunk inside the LDS row
+    int l31, lhi;
+    int xrow_off[TM], xrow_sw[TM], wrow_off[TN], wrow_sw[TN];   // LDS byte offsets of this lane's fragment rows (+ swizzle terms)
     auto swz = [](int r) { return ROWB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
-    long long xbase1, xbase2;     // element offsets of the window start in X / X2 (wave-uniform)
-    int pix0 = 0;
-    if constexpr (CONV) {
-        pix0 = (m0 / (p.Hout * p.Wout)) * p.Hin * p.Win;
-        xbase1 = (long long)pix0 * p.ldx;
-        xbase2 = (long long)pix0 * p.ldx2;
-    } else {
-        xbase1 = bz * p.sX + (long long)m0 * p.ldx;
-        xbase2 = (long long)m0 * p.ldx2;
-    }
-    const __amdgpu_buffer_rsrc_t rs_x1 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + xbase1 * ES), 0, kRecords, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x2 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X2 + xbase2 * ES), 0, kRecords, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.W + (bz * p.sW + (long long)n0 * p.ldw) * ES), 0, kRecords, 0x00020000);
 
+    // addressing state of ONE tile (during a tile's last K slab it is re-pointed at the next tile)
+    int a_m0 = 0, a_n0 = 0, a_bn = 0, a_bz = 0;
+    __amdgpu_buffer_rsrc_t rs_x1, rs_x2, rs_w;
     int xr_[NX];               // dense: row inside the tile (or -1 beyond M); conv: pixel index of the image origin - pix0
     int xay[NX], xax[NX];      // conv: anchor coordinates (oy*stride, ox*stride) or (oy, ox) for upsample
     int xlc[NX];               // byte offset of this lane's logical chunk inside a K tile
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const int r = (wave + NWV * i) * RPI + rg;
-        const int m = m0 + r;
-        xlc[i] = (pc ^ swz(r)) * 16;
-        if constexpr (CONV) {
-            const int hw = p.Hout * p.Wout;
-            const int mc = m < p.M ? m : p.M - 1;
-            const int img = mc / hw;
-            const int rem = mc - img * hw;
-            const int oy = rem / p.Wout;
-            const int ox = rem - oy * p.Wout;
-            const int st = p.mode == 2 ? 2 : 1;
-            xr_[i] = m < p.M ? img * p.Hin * p.Win - pix0 : -1;
-            xay[i] = oy * st;
-            xax[i] = ox * st;
-        } else {
-            xr_[i] = m < p.M ? r : -1;
-            xay[i] = 0;
-            xax[i] = 0;
-        }
-    }
-    unsigned wvo[NW];  // lane byte offsets of the W rows relative to rs_w
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int rw = (wave + NWV * i) * RPI + rg;  // row inside the W panel
-        wvo[i] = (n0 + rw < p.N) ? (unsigned)(rw * p.ldw * ES + (pc ^ swz(BM + rw)) * 16) : kOOB;
-    }
-
-    // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
+    unsigned wvo[NW];          // lane byte offsets of the W rows relative to rs_w
     unsigned xvo[NX];
     int tap = 0, srcsel = 0, seg_left = 0;
     int kx = 0;   // scalar byte offset inside the current X source
     int kwb = 0;  // scalar byte offset along the W rows (all taps and sources are contiguous in K)
+
+    auto setup_tile = [&](int vb) {
+        const int bz = vb / nblk;           // batch index (mode 4: the phase)
+        const int lb = vb - bz * nblk;
+        // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs; remap
+        // (bijectively) so that each XCD - each private L2 - works on one contiguous run of tiles: neighbouring
+        // M tiles of a conv share their halo rows, and all tiles of a run share the same W panel.
+        const int xq = nblk >> 3, xr = nblk & 7;
+        const int xcd = lb & 7, xi = lb >> 3;
+        const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+        // Raster order inside an XCD's run: N is cut into strips of `gn` tiles and a strip is walked N-fastest, so the ~32
+        // workgroups an XCD runs at a time form a (32/gn) x gn block of output tiles - they stream 32/gn activation panels and
+        // gn weight panels through the XCD's 4 MiB L2 instead of 32 + 1 (M-fastest).  Measured with rocprofv3 FETCH_SIZE: the
+        // M-fastest order re-fetched every activation panel once per N tile from the fabric (profiles/round2_*).
+        const int gn = p.tile > 0 ? (p.tile < tiles_n ? p.tile : tiles_n) : 1;
+        const int strip_sz = tiles_m * gn;
+        const int full = tiles_n / gn;
+        int strip = tile_id / strip_sz;
+        int gcols = gn;
+        if (strip >= full) {
+            strip = full;
+            gcols = tiles_n - full * gn;
+        }
+        const int rr = tile_id - strip * strip_sz;
+        const int bm = rr / gcols;
+        const int bn = strip * gn + (rr - bm * gcols);
+        const int m0 = bm * BM;
+        const int n0 = bn * BN;
+        a_m0 = m0;
+        a_n0 = n0;
+        a_bn = bn;
+        a_bz = bz;
+        long long xbase1, xbase2;     // element offsets of the window start in X / X2 (wave-uniform)
+        int pix0 = 0;
+        if constexpr (CONV) {
+            pix0 = (m0 / (p.Hout * p.Wout)) * p.Hin * p.Win;
+            xbase1 = (long long)pix0 * p.ldx;
+            xbase2 = (long long)pix0 * p.ldx2;
+        } else {
+            xbase1 = bz * p.sX + (long long)m0 * p.ldx;
+            xbase2 = (long long)m0 * p.ldx2;
+        }
+        rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + xbase1 * ES), 0, kRecords, 0x00020000);
+        rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X2 + xbase2 * ES), 0, kRecords, 0x00020000);
+        rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + (bz * p.sW + (long long)n0 * p.ldw) * ES), 0, kRecords,
+                                                 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int r = (wave + NWV * i) * RPI + rg;
+            const int m = m0 + r;
+            xlc[i] = (pc ^ swz(r)) * 16;
+            if constexpr (CONV) {
+                const int hw = p.Hout * p.Wout;
+                const int mc = m < p.M ? m : p.M - 1;
+                const int img = mc / hw;
+                const int rem = mc - img * hw;
+                const int oy = rem / p.Wout;
+                const int ox = rem - oy * p.Wout;
+                const int st = p.mode == 2 ? 2 : 1;
+                xr_[i] = m < p.M ? img * p.Hin * p.Win - pix0 : -1;
+                xay[i] = oy * st;
+                xax[i] = ox * st;
+            } else {
+                xr_[i] = m < p.M ? r : -1;
+                xay[i] = 0;
+                xax[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int rw = (wave + NWV * i) * RPI + rg;  // row inside the W panel
+            wvo[i] = (n0 + rw < p.N) ? (unsigned)(rw * p.ldw * ES + (pc ^ swz(BM + rw)) * 16) : kOOB;
+        }
+        tap = 0;
+        srcsel = 0;
+        seg_left = 0;
+        kx = 0;
+        kwb = 0;
+    };
+
+    // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
     const bool two_src = p.C1 < K;
     const int up_shift = p.mode == 3 ? 1 : 0;
     const int ext_y = p.mode == 3 ? p.Hout : p.Hin;  // extent the tap offset is applied in
@@ -168,8 +199,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         if constexpr (CONV) {
             // mode 4 (one phase (py, px) = blockIdx.z of a nearest-2x-upsample + conv3x3, see sdv_hip.h): 2 x 2 taps on the
             // low-resolution grid, rows {y-1+py, y+py}, columns {x-1+px, x+px}
-            const int dy = p.mode == 4 ? (tap >> 1) - 1 + (int)(bz >> 1) : tap / 3 - 1;
-            const int dx = p.mode == 4 ? (tap & 1) - 1 + (int)(bz & 1) : tap - (tap / 3) * 3 - 1;
+            const int dy = p.mode == 4 ? (tap >> 1) - 1 + (a_bz >> 1) : tap / 3 - 1;
+            const int dx = p.mode == 4 ? (tap & 1) - 1 + (a_bz & 1) : tap - (tap / 3) * 3 - 1;
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 int vy = xay[i] + dy, vx = xax[i] + dx;
@@ -190,10 +221,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         seg_left = (srcsel ? K - p.C1 : p.C1) / BK;
     };
 
-    auto stage = [&](int buf) {
-        char* base = smem + buf * TILE_BYTES;
+    // `issue` false: only the bookkeeping of a slab that is already in LDS (the prefetched first slab of a persistent tile)
+    auto stage = [&](int buf, bool issue = true) {
+        char* base = smem + buf * SLOT;
         if (seg_left == 0) new_segment();
         const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
+        if (issue) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int g = wave + NWV * i;
@@ -208,6 +241,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024),
                                                          16, (int)wvo[i], kwb, 0, 0);
         }
+        }
         kx += ROWB;
         kwb += ROWB;
         if (--seg_left == 0) {
@@ -221,36 +255,33 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     };
 
     f32x16_t acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int l31 = lane & 31;
-    const int lhi = lane >> 5;
-
-    // LDS byte offsets of this lane's fragment rows (swizzle term folded per k-step below)
-    int xrow_off[TM], xrow_sw[TM], wrow_off[TN], wrow_sw[TN];
+    auto lane_setup = [&]() {
+        int lk = lane;
+        if constexpr (PERSIST) asm volatile("" : "+v"(lk));
+        rg = lk / CPRW;
+        pc = lk % CPRW;
+        l31 = lk & 31;
+        lhi = lk >> 5;
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-        const int r = wm * TM * 32 + mt * 32 + l31;
-        xrow_off[mt] = r * ROWB;
-        xrow_sw[mt] = swz(r);
-    }
+        for (int mt = 0; mt < TM; ++mt) {
+            const int r = wm * TM * 32 + mt * 32 + l31;
+            xrow_off[mt] = r * ROWB;
+            xrow_sw[mt] = swz(r);
+        }
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        const int r = BM + wn * TN * 32 + nt * 32 + l31;
-        wrow_off[nt] = r * ROWB;
-        wrow_sw[nt] = swz(r);
-    }
+        for (int nt = 0; nt < TN; ++nt) {
+            const int r = BM + wn * TN * 32 + nt * 32 + l31;
+            wrow_off[nt] = r * ROWB;
+            wrow_sw[nt] = swz(r);
+        }
+    };
 
     // Software-pipelined K tile: the fragments of k-step ks+1 are read into a second register set while the
     // MFMAs of k-step ks issue (1 ds_read_b128 slotted behind each MFMA).
     constexpr bool kPipeFrags = TM * TN >= 8;   // big tiles: 1 workgroup / CU, hide LDS latency inside the wave
     auto compute = [&](int buf) {
-        const char* base = smem + buf * TILE_BYTES;
+        const char* base = smem + buf * SLOT;
         if constexpr (ES == 1) {
             // fp8: a K tile is 64 bytes per row = four 16-byte chunks.  One ds_read_b128 of chunk 2j + lhi yields two
             // 8-byte MFMA operands, used for k-steps 2j and 2j+1 (both operands walk K in the same permuted order, so the
@@ -324,6 +355,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 
     const int ntaps = CONV ? (p.mode == 4 ? 4 : 9) : 1;
     const int nkt = (K / BK) * ntaps;
+    // tile walk state: `vb` = the tile being computed, `slot0` = the LDS slot its first K slab is in, `landed` = that slab
+    // was fetched (and waited for) during the tile before
+    int vb = blockIdx.x;
+    int slot0 = 0;
+    bool landed = false;
+    bool has_next = false;
+    auto kloop = [&]() {
     if constexpr (NST > 2) {
         // ---- ring main loop ------------------------------------------------------------------------------
         static_assert(KSTEPS == 2, "ring tiles are 32 wide in K");
@@ -447,16 +485,33 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         body(std::false_type{}, std::false_type{}, 0);
     } else {
     // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
-    stage(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage(slot0, !landed);
+    // (a prefetched first slab was waited for before the previous tile's epilogue barrier; waiting again here would
+    //  also wait for that epilogue's STORES, which may drain behind this tile's first MFMAs instead)
+    if (!(PERSIST && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int kt = 0; kt + 1 < nkt; ++kt) {
         __syncthreads();
-        if (kt + 1 < nkt) stage((kt + 1) & 1);
-        compute(kt & 1);
+        stage((slot0 + kt + 1) & 1);
+        compute((slot0 + kt) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // last K slab (kept out of the loop: the re-pointing below must not add register pressure to the steady state)
+    __syncthreads();
+    if (PERSIST && has_next) {
+        // every wave is past the MFMAs of slab nkt-2, so its slot is free - point the addressing at the next tile and
+        // start its first slab
+        setup_tile(vb + (int)gridDim.x);
+        stage((slot0 + nkt) & 1);
     }
+    compute((slot0 + nkt - 1) & 1);
+    }
+    };
 
     // ---- epilogue ------------------------------------------------------------------------------
+    int e_m0, e_n0, e_bn, e_bzi;
+    auto epilogue = [&]() {
+    const int m0 = e_m0, n0 = e_n0, bn = e_bn;
+    const long long bz = e_bzi;
     const float alpha = p.alpha;
     const int acols = p.alpha_cols > 0 ? p.alpha_cols : 0x7fffffff;
     const float* bias = p.bias;
@@ -488,13 +543,16 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                              ((((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0) &&
                              (((p.sC | p.sR) & 7) == 0);
         if (aligned) {
-            float* stg = (float*)smem + wave * (32 * 64);
-            float* rowacc = (float*)smem + NWV * (32 * 64) + wave * 64;   // (sum, sumsq) of this wave's 32 rows (stats_out)
+            // (PERSIST: the slabs alias the slot the last K slab was read from - the other one is receiving the next tile)
+            char* const stg_region = PERSIST ? smem + ((slot0 + nkt - 1) & 1) * SLOT : smem;
+            char* const vec_region = PERSIST ? smem + 2 * SLOT : smem + SLABS;
+            float* stg = (float*)stg_region + wave * (32 * 64);
+            float* rowacc = (float*)vec_region + wave * 64;   // (sum, sumsq) of this wave's 32 rows (stats_out)
             // Per-column epilogue vectors of this tile's BN columns, staged in LDS ONCE per tile: bias, the LayerNorm-fold row
             // sums s (ln_side 1) or the per-column (mean, rstd) (ln_side 2).  Reading them per accumulator quad straight from
             // global memory cost 3.7 us per 256 x 320 tile per vector (20 dependent 16-byte loads per m-tile and lane):
             // "+bias" alone was +16 % on the K = 320 projections (profiles/round1_gemm_overhead.txt).
-            float* vbias = (float*)smem + NWV * (32 * 64 + 64);
+            float* vbias = (float*)vec_region + NWV * 64;
             float* vaux = vbias + BN;            // [BN] (ln_side 1) or [BN][2] (ln_side 2)
             // per-ROW LayerNorm-fold operands of this lane's TM rows, fetched once (before the barrier: their latency hides
             // behind it): ln_side 1 -> (mean, rstd) of the row, ln_side 2 -> s of the row
@@ -514,6 +572,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     if (mrow < p.M) ln_row[mt][0] = p.ln_s[mrow];
                 }
             }
+            // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
+            // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
+            if (PERSIST && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // every wave has left the K loop: the tile buffers may be overwritten
             {
                 constexpr int lnsd = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
@@ -713,6 +774,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     }
 
     // ---- fallback epilogue straight from the MFMA registers (odd leading dims / N, e.g. the 77-token V^T) ----
+    if (PERSIST && has_next) {   // (as above: the next tile's first slab is waited for here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (geglu) {
         const int nout = p.N >> 1;
 #pragma unroll
@@ -809,14 +874,58 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 }
             }
         }
+    };
+
+    // ---- the tile walk -------------------------------------------------------------------------------------------
+    for (;;) {
+        lane_setup();
+        {
+            int v = vb;
+            if constexpr (PERSIST) asm volatile("" : "+s"(v));   // (recomputed, not carried across the previous epilogue)
+            setup_tile(v);
+        }
+        e_m0 = a_m0;
+        e_n0 = a_n0;
+        e_bn = a_bn;
+        e_bzi = a_bz;
+        has_next = PERSIST && vb + (int)gridDim.x < total;
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        kloop();
+        epilogue();
+        if (!has_next) break;
+        vb += (int)gridDim.x;
+        slot0 = (slot0 + nkt) & 1;
+        landed = true;
+    }
+}
+
+int g_persistent = 1;   // sdv_gemm_set_persistent(): A/B switch for tools/ (0 = one workgroup per tile, as in round 1)
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
 }
 
 template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT = 0>
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int TILES = NST * (BM + BN) * BK * (FEAT == 8 ? 1 : 2);
-    constexpr int STG = WM * WN * (32 * 64 * 4 + 256) + 3 * BN * 4;   // fp32 staging slabs of the epilogue + row-stat accumulators + column vectors
-    constexpr int LDS = TILES > STG ? TILES : STG;
+    constexpr int TILE_BYTES = (BM + BN) * BK * (FEAT == 8 ? 1 : 2);
+    constexpr int SLABS = WM * WN * 32 * 64 * 4;                       // fp32 staging slabs of the epilogue
+    constexpr int VECS = WM * WN * 256 + 3 * BN * 4;                   // row-stat accumulators + column vectors
+    constexpr bool PERSIST = WM * WN == 8 && NST == 2;                 // (see the kernel: slabs alias ONE K-slab slot)
+    constexpr int SLOT = TILE_BYTES > SLABS ? TILE_BYTES : SLABS;
+    constexpr int LDS = PERSIST ? 2 * SLOT + VECS : (NST * TILE_BYTES > SLABS + VECS ? NST * TILE_BYTES : SLABS + VECS);
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
@@ -825,7 +934,9 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
+    const long long total = (long long)tiles_m * tiles_n * (a.batch > 0 ? a.batch : 1);
+    SDV_REQUIRE(total < 0x7fffffffLL, "sdv_gemm_bf16: too many tiles");
+    dim3 grid((unsigned)(PERSIST && g_persistent && total > num_cus() ? num_cus() : total), 1, 1);
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>), grid, dim3(WM * WN * 64), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
@@ -862,6 +973,14 @@ extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) { return s
 // Number of (sum, sumsq) slots per output row that sdv_gemm_bf16 would write to `stats_out` for these arguments
 // (= N tiles x wave columns of the tile the launch would pick); the caller sizes stats_out as [batch][M][slots][2] floats.
 extern "C" int sdv_gemm_stats_slots(const sdv_gemm_args* args) { return sdv_gemm_impl(args, nullptr, true); }
+
+// 1 (default): the 8-wave tiles run as persistent workgroups (one per CU, walking tiles); 0: one workgroup per tile.  Returns
+// the previous setting.  Results are identical either way; this exists so tools/ can time both on the same box.
+extern "C" int sdv_gemm_set_persistent(int on) {
+    const int prev = g_persistent;
+    g_persistent = on ? 1 : 0;
+    return prev;
+}
 
 static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only) {
     SDV_REQUIRE(args != nullptr, "sdv_gemm_bf16: null args");
@@ -973,7 +1092,9 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     if (plan_only) return a.stats_p;
     SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     switch (tile) {
-#ifndef SDV_GEMM_RING_ONLY   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
+#ifdef SDV_GEMM_ONLY_TILE6   // (tools: compile the 256 x 320 tile alone for resource / ISA inspection)
+        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true>(a, s);
+#elif !defined(SDV_GEMM_RING_ONLY)   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
         case 1: return launch_igemm<2, 2, 2, 2, 64, 2, true>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
         case 3: return launch_igemm<2, 2, 1, 1, 64>(a, s);    //  64 x  64
@@ -985,8 +1106,10 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         case 10: return launch_igemm<4, 1, 2, 1, 64>(a, s);   // 256 x  32, 4 waves (RRDB growth convs, Cout = 32)
         case 11: return launch_igemm<4, 1, 2, 2, 64>(a, s);   // 256 x  64, 4 waves
 #endif
+#ifndef SDV_GEMM_ONLY_TILE6
         case 12: return launch_igemm<4, 2, 2, 5, 32, 4>(a, s);   // 256 x 320, 8 waves, ring of four 32-wide K tiles
         case 13: return launch_igemm<4, 2, 2, 4, 32, 4>(a, s);   // 256 x 256, 8 waves, ring
+#endif
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
     return SDV_OK;

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "sdv_abi_version": (C.c_int, []),
     "sdv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "sdv_gemm_stats_slots": (C.c_int, [C.POINTER(GemmArgs)]),
+    "sdv_gemm_set_persistent": (C.c_int, [C.c_int]),
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
