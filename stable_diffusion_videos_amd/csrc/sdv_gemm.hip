@@ -28,6 +28,18 @@
 
 namespace {
 
+#ifdef SDV_GEMM_TIMING   // tools only: per-phase s_memtime stamps of workgroup 0 / wave 0 (never defined in the product build)
+__device__ long long* g_tbuf = nullptr;
+#define SDV_STAMP(slot)                                                                        \
+    do {                                                                                       \
+        if (g_tbuf && blockIdx.x == SDV_GEMM_TIMING && threadIdx.x == 0 && tstamp < 4096) {    \
+            g_tbuf[tstamp++] = ((long long)(slot) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffLL); \
+        }                                                                                      \
+    } while (0)
+#else
+#define SDV_STAMP(slot) do {} while (0)
+#endif
+
 // waves per SIMD the register allocator must leave room for: the 32-wide-K tiles are meant to run two workgroups
 // per CU (16 waves -> 4 per SIMD -> <= 128 VGPRs)
 // NST = K-tile buffers in LDS.  2: double buffer, one `vmcnt(0)` + barrier per tile (the small / 64-wide-K tiles).
@@ -61,6 +73,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     static_assert(FEAT != 8 || (BK == 64 && NST == 2), "fp8 tiles: 64 elements (64 bytes) per K tile, double buffered");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef SDV_GEMM_TIMING
+    int tstamp = 0;
+#endif
+    SDV_STAMP(0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,10 +92,14 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     // K = 320 tile, profiles/round2_gemm_overhead.txt), and the CUs stop moving through load / compute / store phases in
     // lockstep.  Every other tile runs this loop exactly once (grid = tiles).
     constexpr bool PERSIST = NWV == 8 && NST == 2;
-    // LDS: [slot 0][slot 1] K-slab buffers of SLOT bytes, then the epilogue's small vectors.  The fp32 staging slabs of the
-    // epilogue alias the slot the tile's LAST K slab was read from; the other slot already receives the next tile.
-    constexpr int SLABS = NWV * 32 * 64 * 4;
-    constexpr int SLOT = PERSIST ? (TILE_BYTES > SLABS ? TILE_BYTES : SLABS) : TILE_BYTES;
+    // LDS: NST K-slab buffers of SLOT bytes, then the epilogue's column vectors (3 x BN floats) and row accumulators.  The
+    // epilogue's staging slabs (SLAB bytes per wave) alias the K-slab buffers - in a persistent workgroup the ONE slot the
+    // tile's last K slab was read from, the other slot already receives the next tile.
+    constexpr int SLAB = 32 * 144;   // 32 rows x (128 + 16 pad) bytes
+    constexpr int SLOT = PERSIST ? (TILE_BYTES > 2 * NWV * SLAB ? TILE_BYTES : 2 * NWV * SLAB) : TILE_BYTES;
+    // two slabs per wave (pass p+1 is parked while pass p is read back) wherever the K-slab buffers have the room
+    constexpr bool DBL = (PERSIST ? SLOT : NST * SLOT) >= 2 * NWV * SLAB;
+    static_assert(NST * SLOT >= NWV * SLAB, "the staging slabs must fit the K-slab buffers");
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int nblk = tiles_m * tiles_n;
@@ -533,49 +553,69 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     const bool geglu = p.epi == 1;
     const int wcol0 = n0 + wn * TN * 32;  // first (permuted, for GEGLU) weight row of this wave
 
-    // ---- staged epilogue (the normal case): per pass the wave parks 32 rows x 64 columns (two n-tiles) of fp32
-    //      in its private LDS slab (XOR-swizzled 16-B chunks: conflict-free b128 writes and row reads), then writes
-    //      whole 128-byte row segments; the residual rows of the pass are fetched BEFORE the LDS phase so their
-    //      latency hides behind it. ----
+    // ---- the normal case: row-major 16-byte stores through a per-wave LDS slab ----
     {
         const int ncols_out = geglu ? (p.N >> 1) : p.N;
         const bool aligned = ((p.ldc & 7) == 0) && ((ncols_out & 7) == 0) && (!R || (p.ldr & 7) == 0) &&
                              ((((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0) &&
                              (((p.sC | p.sR) & 7) == 0);
-        if (aligned) {
-            // (PERSIST: the slabs alias the slot the last K slab was read from - the other one is receiving the next tile)
+        // (the 8-wave tiles compile the three common store sequences only: SiLU - the one extra activation they offer, used
+        //  by no network here - takes the register-direct path below; the 4-wave tiles carry the generic sequence as well)
+        if (aligned && (XACT || p.epi == 0 || (geglu && !R))) {
+            // Staged stores: the MFMA leaves lane (l31, lhi) with row l31 and, per accumulator quad, 4 consecutive columns -
+            // stored as they are, every 16-byte piece of a wave's store instruction lies in a different row, and the texture
+            // addresser takes them one by one (measured: 9.5k clocks for the 160 stores of a 256 x 320 tile, the whole K loop
+            // of a K = 320 tile is 13k MFMA clocks).  So each wave parks a PASS - 32 rows x 64 bf16 (or 32 fp32 when a
+            // residual has to be added before the single rounding) - in its private 4.5 KB LDS slab and reads it back
+            // row-major: 8 (4) adjacent lanes then hold one row's 128 (64) contiguous bytes.  The passes are software
+            // pipelined - values of pass p+1 are converted and written while the rows of pass p are still in flight from LDS
+            // (two slabs per wave where LDS allows, fenced hand-overs) - the code is straight-line per
+            // case (no runtime flags in the common ones), and rows beyond M / columns beyond N are dropped by the buffer
+            // descriptor's range check instead of exec-mask branches.
+            // (an opaque copy of the lane id: everything derived from it below is tile-invariant, and hoisted out of the
+            //  persistent tile loop it would sit in ~17 registers across the K loop - they spilled)
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            // (LDS slab accesses go through may_alias types: the slab is written as 8-byte / 16-byte pieces in one layout and
+            //  read back as 16-byte pieces in another, and type-based alias analysis must not reorder the two)
+            typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) slab_u4;
+            typedef unsigned int __attribute__((ext_vector_type(2), may_alias)) slab_u2;
             char* const stg_region = PERSIST ? smem + ((slot0 + nkt - 1) & 1) * SLOT : smem;
-            char* const vec_region = PERSIST ? smem + 2 * SLOT : smem + SLABS;
-            float* stg = (float*)stg_region + wave * (32 * 64);
-            float* rowacc = (float*)vec_region + wave * 64;   // (sum, sumsq) of this wave's 32 rows (stats_out)
-            // Per-column epilogue vectors of this tile's BN columns, staged in LDS ONCE per tile: bias, the LayerNorm-fold row
-            // sums s (ln_side 1) or the per-column (mean, rstd) (ln_side 2).  Reading them per accumulator quad straight from
-            // global memory cost 3.7 us per 256 x 320 tile per vector (20 dependent 16-byte loads per m-tile and lane):
-            // "+bias" alone was +16 % on the K = 320 projections (profiles/round1_gemm_overhead.txt).
-            float* vbias = (float*)vec_region + NWV * 64;
+            char* const slab0 = stg_region + wave * (DBL ? 2 : 1) * SLAB;
+            auto slab_of = [&](int pi) { return slab0 + (DBL ? (pi & 1) * SLAB : 0); };
+            // Per-column epilogue vectors of this tile's BN columns, staged in LDS ONCE per tile (their own region behind the
+            // K-slab buffers): bias, the LayerNorm-fold row sums s (ln_side 1) or the per-column (mean, rstd) (ln_side 2).
+            float* vbias = (float*)(smem + NST * SLOT);
             float* vaux = vbias + BN;            // [BN] (ln_side 1) or [BN][2] (ln_side 2)
-            // per-ROW LayerNorm-fold operands of this lane's TM rows, fetched once (before the barrier: their latency hides
-            // behind it): ln_side 1 -> (mean, rstd) of the row, ln_side 2 -> s of the row
-            float ln_row[TM][2];
+            float* rowacc = vbias + 3 * BN + wave * 64;   // FEAT 3: (sum, sumsq) of this wave's 32 rows of the current m-tile
+            const int mfirst = m0 < p.M ? m0 : p.M - 1;
+            const long long orow0 = out_row(mfirst);
+            const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(C + orow0 * p.ldc), 0, kRecords, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_r =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(R ? R + orow0 * p.ldr : C), 0, kRecords, 0x00020000);
+            // per-ROW operands of this lane's TM accumulator rows, fetched before the barrier (their latency hides behind it):
+            // LayerNorm fold: ln_side 1 -> (mean, rstd) of the row, ln_side 2 -> s of the row; bias_mode 2: the row's bias
+            float ln_row[TM][2], bm_[TM];
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 ln_row[mt][0] = 0.f;
                 ln_row[mt][1] = 1.f;
                 const int mrow = m0 + wm * TM * 32 + mt * 32 + l31;
+                const bool ok = mrow < p.M;
+                bm_[mt] = (bias && p.bias_mode == 2 && ok) ? bias[mrow] : 0.f;
                 if constexpr (FEAT == 1) {
-                    if (mrow < p.M) {
+                    if (ok) {
                         const float2 st = *(const float2*)(p.ln_stats + 2 * (bz * p.M + mrow));
                         ln_row[mt][0] = st.x;
                         ln_row[mt][1] = st.y;
                     }
                 } else if constexpr (FEAT == 2) {
-                    if (mrow < p.M) ln_row[mt][0] = p.ln_s[mrow];
+                    if (ok) ln_row[mt][0] = p.ln_s[mrow];
                 }
             }
             // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
             // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
             if (PERSIST && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // every wave has left the K loop: the tile buffers may be overwritten
             {
                 constexpr int lnsd = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
                 const bool col_bias = bias && p.bias_mode == 1;
@@ -590,185 +630,294 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     }
                 }
             }
-            __syncthreads();
-            // one pass: n-tiles [nt0, nt0+ntc) of m-tile mt -> OC output columns starting at ocol
-            auto pass = [&](auto oc_tag, int mt, int nt0, int ocol) {
-                constexpr int OC = decltype(oc_tag)::value;   // 64 / 32 / 16 output columns
-                constexpr int CPO = OC / 8;                   // 16-byte bf16 chunks per output row
-                constexpr int ITERS = 32 * CPO / 64;
-                const int mbase = m0 + wm * TM * 32 + mt * 32;
-                // The swizzled slab addresses are 1-2 VALU each; opaque per-pass copies of the lane ids keep the compiler from
-                // hoisting all of them (16 registers) above the passes, where the 160 accumulator registers are still live
-                // (the 256 x 320 ring tile spilled 18 registers there).
-                int lane_p = lane, l31_p = l31;
-                asm volatile("" : "+v"(lane_p), "+v"(l31_p));
-                bf16x8_raw rres[ITERS];
-                if (R) {
-#pragma unroll
-                    for (int it = 0; it < ITERS; ++it) {
-                        const int idx = lane_p + it * 64;
-                        const int r = idx / CPO, cj = idx % CPO;
-                        const int m = mbase + r, n = ocol + cj * 8;
-                        if (m < p.M && n < ncols_out) rres[it] = *(const bf16x8_raw*)(R + out_row(m) * p.ldr + n);
+            SDV_STAMP(5);
+            __syncthreads();   // the vectors are staged AND every wave has left the K loop (the slabs alias a K-slab buffer)
+            SDV_STAMP(3);
+            // LayerNorm folded into this GEMM (sdv_hip.h "ln_side"): the weights were pre-multiplied by gamma, so
+            //   LN(x) W^T = rstd * (x (gamma o W)^T - mean * s) + (W beta + b),  s = row sums of gamma o W
+            // side 1: (mean, rstd) belong to the output ROW (this lane's m), s to the output column;
+            // side 2 (the transposed V^T projection): (mean, rstd) belong to the output COLUMN, s to the row.
+            constexpr int ln_side = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
+
+            // the 4 values of accumulator quad q of tile (nt, mt) with scale / LayerNorm fold / bias applied (GEGLU: W rows
+            // are interleaved [16 value | 16 gate] per 32-row MFMA tile, so quads g and g+2 of a lane hold the value and the
+            // gate of the SAME 4 channels -> quad g in {0, 1} yields 4 of the n-tile's 16 output columns)
+            auto quad_vals = [&](bool gg, int nt, int mt, int q, int z, float* v) {   // z: an opaque 0 (see park)
+                if (gg) {
+                    const float ln_mu = ln_row[mt][0], ar = alpha * ln_row[mt][1];
+                    const int nv = wcol0 + nt * 32 + 8 * q + 4 * lhi - n0 + z;
+                    const float4 bv = *(const float4*)(vbias + nv), bg = *(const float4*)(vbias + nv + 16);
+                    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = sv;
+                    if constexpr (ln_side == 1) {
+                        sv = *(const float4*)(vaux + nv);
+                        sg = *(const float4*)(vaux + nv + 16);
                     }
+                    const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
+                    const float svv[4] = {sv.x, sv.y, sv.z, sv.w}, sgv[4] = {sg.x, sg.y, sg.z, sg.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = ((acc[nt][mt][4 * q + e] - ln_mu * svv[e]) * ar + bvv[e]) *
+                               gelu_erf_f((acc[nt][mt][4 * (q + 2) + e] - ln_mu * sgv[e]) * ar + bgv[e]);
+                    return;
                 }
-                const int mrow = mbase + l31;
-                const float bm_ = (bias && p.bias_mode == 2 && mrow < p.M) ? bias[mrow] : 0.f;
-                // LayerNorm folded into this GEMM (sdv_hip.h "ln_side"): the weights were pre-multiplied by gamma, so
-                //   LN(x) W^T = rstd * (x (gamma o W)^T - mean * s) + (W beta + b),  s = row sums of gamma o W
-                // side 1: (mean, rstd) belong to the output ROW (this lane's m), s to the output column;
-                // side 2 (the transposed V^T projection): (mean, rstd) belong to the output COLUMN, s to the row.
-                constexpr int ln_side = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
-                float* const stats_out = FEAT == 3 ? p.stats_out : nullptr;
-                const float ln_mu = ln_row[mt][0], ln_rs = ln_row[mt][1], ln_sm = ln_row[mt][0];
-                if (geglu) {
-                    // W rows are interleaved [16 value | 16 gate] per 32-row MFMA tile: accumulator quads g and g+2 of
-                    // a lane hold the value and the gate of the SAME 4 channels -> 16 output columns per n-tile
+                const int nb = wcol0 + nt * 32 + 8 * q + 4 * lhi;
+                const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
+                const float4 bq = *(const float4*)(vbias + (nb - n0) + z);
+                const float bvv[4] = {bq.x + bm_[mt], bq.y + bm_[mt], bq.z + bm_[mt], bq.w + bm_[mt]};
+                if constexpr (ln_side == 1) {
+                    const float4 s4 = *(const float4*)(vaux + (nb - n0) + z);
+                    const float sv4[4] = {s4.x, s4.y, s4.z, s4.w};
+                    const float ar = al * ln_row[mt][1];
 #pragma unroll
-                    for (int j = 0; j < OC / 16; ++j)
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[nt][mt][4 * q + e] - ln_row[mt][0] * sv4[e]) * ar + bvv[e];
+                } else if constexpr (ln_side == 2) {
+                    const float4 st0 = *(const float4*)(vaux + 2 * (nb - n0 + z));       // (mean, rstd) of columns nb, nb+1
+                    const float4 st1 = *(const float4*)(vaux + 2 * (nb - n0 + z) + 4);   //                 nb+2, nb+3
+                    const float mu4[4] = {st0.x, st0.z, st1.x, st1.z}, rs4[4] = {st0.y, st0.w, st1.y, st1.w};
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            const int nt = nt0 + j;
-                            const int nv = wcol0 + nt * 32 + 8 * g + 4 * lhi;
-                            const float4 bv = *(const float4*)(vbias + (nv - n0));
-                            const float4 bg = *(const float4*)(vbias + (nv - n0) + 16);
-                            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = sv;
-                            if constexpr (ln_side == 1) {
-                                sv = *(const float4*)(vaux + (nv - n0));
-                                sg = *(const float4*)(vaux + (nv - n0) + 16);
-                            }
-                            const float ar = alpha * ln_rs;
-                            float4 o;
-                            o.x = ((acc[nt][mt][4 * g + 0] - ln_mu * sv.x) * ar + bv.x) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 0] - ln_mu * sg.x) * ar + bg.x);
-                            o.y = ((acc[nt][mt][4 * g + 1] - ln_mu * sv.y) * ar + bv.y) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 1] - ln_mu * sg.y) * ar + bg.y);
-                            o.z = ((acc[nt][mt][4 * g + 2] - ln_mu * sv.z) * ar + bv.z) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 2] - ln_mu * sg.z) * ar + bg.z);
-                            o.w = ((acc[nt][mt][4 * g + 3] - ln_mu * sv.w) * ar + bv.w) * gelu_erf_f((acc[nt][mt][4 * (g + 2) + 3] - ln_mu * sg.w) * ar + bg.w);
-                            const int chunk = j * 4 + 2 * g + lhi;
-                            *(float4*)(stg + l31_p * 64 + ((chunk ^ (l31_p & 7)) << 2)) = o;
-                        }
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[nt][mt][4 * q + e] - mu4[e] * ln_row[mt][0]) * (rs4[e] * al) + bvv[e];
                 } else {
 #pragma unroll
-                    for (int j = 0; j < OC / 32; ++j)
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int nt = nt0 + j;
-                            const int nb = wcol0 + nt * 32 + 8 * g4 + 4 * lhi;
-                            float4 bv = *(const float4*)(vbias + (nb - n0));
-                            bv.x += bm_;
-                            bv.y += bm_;
-                            bv.z += bm_;
-                            bv.w += bm_;
-                            float4 o;
-                            const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
-                            if constexpr (ln_side == 1) {
-                                const float4 s4 = *(const float4*)(vaux + (nb - n0));
-                                const float ar = al * ln_rs;
-                                o.x = (acc[nt][mt][4 * g4 + 0] - ln_mu * s4.x) * ar + bv.x;
-                                o.y = (acc[nt][mt][4 * g4 + 1] - ln_mu * s4.y) * ar + bv.y;
-                                o.z = (acc[nt][mt][4 * g4 + 2] - ln_mu * s4.z) * ar + bv.z;
-                                o.w = (acc[nt][mt][4 * g4 + 3] - ln_mu * s4.w) * ar + bv.w;
-                            } else if constexpr (ln_side == 2) {
-                                const float4 st0 = *(const float4*)(vaux + 2 * (nb - n0));       // (mean, rstd) of columns nb, nb+1
-                                const float4 st1 = *(const float4*)(vaux + 2 * (nb - n0) + 4);   //                 nb+2, nb+3
-                                o.x = (acc[nt][mt][4 * g4 + 0] - st0.x * ln_sm) * (st0.y * al) + bv.x;
-                                o.y = (acc[nt][mt][4 * g4 + 1] - st0.z * ln_sm) * (st0.w * al) + bv.y;
-                                o.z = (acc[nt][mt][4 * g4 + 2] - st1.x * ln_sm) * (st1.y * al) + bv.z;
-                                o.w = (acc[nt][mt][4 * g4 + 3] - st1.z * ln_sm) * (st1.w * al) + bv.w;
-                            } else {
-                                o.x = acc[nt][mt][4 * g4 + 0] * al + bv.x;
-                                o.y = acc[nt][mt][4 * g4 + 1] * al + bv.y;
-                                o.z = acc[nt][mt][4 * g4 + 2] * al + bv.z;
-                                o.w = acc[nt][mt][4 * g4 + 3] * al + bv.w;
-                            }
-                            const int chunk = j * 8 + 2 * g4 + lhi;
-                            *(float4*)(stg + l31_p * 64 + ((chunk ^ (l31_p & 7)) << 2)) = o;
-                        }
-                }
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int idx = lane_p + it * 64;
-                    const int r = idx / CPO, cj = idx % CPO;
-                    const int m = mbase + r, n = ocol + cj * 8;
-                    float s1 = 0.f, s2 = 0.f;
-                    if (m < p.M && n < ncols_out) {
-                        const float4 a = *(const float4*)(stg + r * 64 + (((2 * cj) ^ (r & 7)) << 2));
-                        const float4 b = *(const float4*)(stg + r * 64 + (((2 * cj + 1) ^ (r & 7)) << 2));
-                        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                        if (R) {
-                            float g[8];
-                            unpack8(rres[it], g);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += g[e];
-                        }
-                        if (p.epi == 2) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
-                        }
-                        if constexpr (XACT) {
-                            if (p.epi == 3) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) f[e] = lrelu02_f(f[e]);
-                            } else if (p.epi == 4) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
-                            } else if (p.epi == 5) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
-                            }
-                        }
-                        const bf16x8_raw packed = pack8(f);
-                        *(bf16x8_raw*)(C + out_row(m) * p.ldc + n) = packed;
-                        if (stats_out) {   // LayerNorm statistics of the values as STORED (bf16), for the consumer's fold
-                            float g[8];
-                            unpack8(packed, g);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                s1 += g[e];
-                                s2 = __builtin_fmaf(g[e], g[e], s2);
-                            }
-                        }
-                    }
-                    if (stats_out) {
-                        // the CPO lanes that share a row are neighbours: butterfly over them, lane cj == 0 adds the pass's
-                        // partial to the wave's per-row accumulators in LDS (same wave -> ordered)
-                        if constexpr (CPO >= 2) {
-                            s1 += __shfl_xor(s1, 1);
-                            s2 += __shfl_xor(s2, 1);
-                        }
-                        if constexpr (CPO >= 4) {
-                            s1 += __shfl_xor(s1, 2);
-                            s2 += __shfl_xor(s2, 2);
-                        }
-                        if constexpr (CPO >= 8) {
-                            s1 += __shfl_xor(s1, 4);
-                            s2 += __shfl_xor(s2, 4);
-                        }
-                        if (cj == 0) {
-                            atomicAdd(rowacc + 2 * r, s1);
-                            atomicAdd(rowacc + 2 * r + 1, s2);
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * q + e] * al + bvv[e];
                 }
             };
+
+            // One straight-line pass sequence per case:
+            // 0 = bias only (bf16 slab, 2 n-tiles per pass; 4 = the same for the phase up-conv's scattered output rows), 1 = + residual (fp32 slab, 1 n-tile per pass), 2 = GEGLU (bf16
+            // slab, 4 n-tiles = 64 output columns per pass), 3 = everything else (activations, GEGLU + residual) on runtime
+            // flags (fp32 slab, 1 n-tile per pass).
+            auto run = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                constexpr bool F32 = MODE == 1 || MODE == 3;
+                const bool gg = MODE == 2 || (MODE == 3 && geglu);
+                const bool has_r = MODE == 1 || (MODE == 3 && R != nullptr);
+                constexpr int NPT = (MODE == 0 || MODE == 4) ? 2 : (MODE == 2 ? 4 : 1);   // n-tiles per pass
+                constexpr int PP = (TN + NPT - 1) / NPT;                    // passes per m-tile
+                constexpr int NP = TM * PP;
+                constexpr int MAXIT = F32 ? 2 : 4;                          // 64-lane iterations of the row-major phase
+                constexpr int DEPTH = (FEAT == 0 || FEAT == 8) ? 2 : 1, RING = DEPTH + 1;   // residual rows are fetched DEPTH passes ahead
+                // geometry of pass pi
+                auto p_mt = [&](int pi) { return pi / PP; };
+                auto p_nt0 = [&](int pi) { return (pi % PP) * NPT; };
+                auto p_cnt = [&](int pi) { return TN - p_nt0(pi) < NPT ? TN - p_nt0(pi) : NPT; };
+                auto p_oc = [&](int pi) { return p_cnt(pi) * (gg ? 16 : 32); };                     // output columns
+                auto p_col0 = [&](int pi) { return gg ? (wcol0 >> 1) + p_nt0(pi) * 16 : wcol0 + p_nt0(pi) * 32; };
+                // item `it` of the row-major phase of pass pi: lane -> (row r of the m-tile, 8-column group cj).  The lane part of
+                // its byte offset inside C / R goes into the VGPR offset (past num_records when the row or the column group
+                // is outside the matrix), the pass part - m-tile row, first column - is wave-uniform and rides in the SGPR offset.
+                auto item = [&](int pi, int it, int& r, int& cj, unsigned& vo_c, unsigned& vo_r) {
+                    const int cpo = p_oc(pi) >> 3;          // 8-column groups per row: 8, 4 or 2
+                    const int idx = lane_e + 64 * it;
+                    r = idx / cpo;
+                    cj = idx - r * cpo;
+                    const int rows_left = p.M - (m0 + wm * TM * 32 + p_mt(pi) * 32);
+                    const int cols_left = ncols_out - p_col0(pi);
+                    const bool ok = r < rows_left && cj * 8 < cols_left;
+                    if constexpr (MODE == 4) {   // phase up-conv: the output row is not linear in m
+                        const long long d = out_row(ok ? m0 + wm * TM * 32 + p_mt(pi) * 32 + r : mfirst) - orow0;
+                        vo_c = ok ? (unsigned)(d * p.ldc + p_col0(pi) + cj * 8) * 2u : kOOB;
+                        vo_r = kOOB;
+                    } else {
+                        vo_c = ok ? (unsigned)(r * p.ldc + cj * 8) * 2u : kOOB;
+                        vo_r = ok ? (unsigned)(r * p.ldr + cj * 8) * 2u : kOOB;
+                    }
+                };
+                auto soff = [&](int pi, int ld) {   // wave-uniform part of the byte offset (not range-checked by the hardware)
+                    if constexpr (MODE == 4) return 0;
+                    return ((m0 - mfirst + wm * TM * 32 + p_mt(pi) * 32) * ld + p_col0(pi)) * 2;
+                };
+                auto n_iters = [&](int pi) { return (4 * p_oc(pi) + 63) / 64; };   // 32 rows x OC/8 items over 64 lanes
+
+                // phase 1 of pass pi: scale / fold / bias (/ GEGLU) in the MFMA layout, park the values in the slab
+                auto park = [&](int pi) {
+                    const int mt = p_mt(pi);
+                    char* const slab = slab_of(pi);
+                    // (an opaque 0 in the vector indices: the two m-tiles read the SAME bias / fold vectors, and the compiler
+                    //  would otherwise keep the first m-tile's 8 registers per quad alive for the second - they spilled)
+                    int z = 0;
+                    asm volatile("" : "+v"(z));
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                if (FEAT == 3 && p.stats_out) rowacc[lane] = 0.f;
-                if (geglu) {
+                    for (int k = 0; k < NPT; ++k) {
+                        if (k >= p_cnt(pi)) continue;
+                        const int nt = p_nt0(pi) + k;
 #pragma unroll
-                    for (int nt = 0; nt + 1 < TN; nt += 2) pass(std::integral_constant<int, 32>{}, mt, nt, (wcol0 >> 1) + nt * 16);
-                    if constexpr (TN % 2 == 1) pass(std::integral_constant<int, 16>{}, mt, TN - 1, (wcol0 >> 1) + (TN - 1) * 16);
-                } else {
+                        for (int q = 0; q < 4; ++q) {
+                            if (gg && q >= 2) continue;
+                            float v[4];
+                            quad_vals(gg, nt, mt, q, z, v);
+                            const int cl = (gg ? k * 16 : k * 32) + 8 * q + 4 * lhi;   // column inside the pass
+                            if constexpr (F32) {
+                                *(slab_u4*)(slab + l31 * 144 + cl * 4) =
+                                    slab_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                            } else {
+                                const slab_u2 pv = slab_u2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                                *(slab_u2*)(slab + l31 * 144 + cl * 2) = pv;
+                            }
+                        }
+                    }
+                };
+                // phase 2a: issue the row-major reads of pass pi
+                u32x4_t rd[MAXIT][F32 ? 2 : 1];
+                auto fetch = [&](int pi) {
+                    const char* const slab = slab_of(pi);
 #pragma unroll
-                    for (int nt = 0; nt + 1 < TN; nt += 2) pass(std::integral_constant<int, 64>{}, mt, nt, wcol0 + nt * 32);
-                    if constexpr (TN % 2 == 1) pass(std::integral_constant<int, 32>{}, mt, TN - 1, wcol0 + (TN - 1) * 32);
+                    for (int it = 0; it < MAXIT; ++it) {
+                        if (it >= n_iters(pi)) continue;
+                        int r, cj;
+                        unsigned a, b;
+                        item(pi, it, r, cj, a, b);
+                        if constexpr (F32) {
+                            rd[it][0] = *(const slab_u4*)(slab + r * 144 + cj * 32);
+                            rd[it][1] = *(const slab_u4*)(slab + r * 144 + cj * 32 + 16);
+                        } else {
+                            rd[it][0] = *(const slab_u4*)(slab + r * 144 + cj * 16);
+                        }
+                    }
+                };
+                // residual rows of pass pi, straight in the row-major layout
+                u32x4_t rres[F32 ? RING : 1][MAXIT];
+                auto load_res = [&](int pi) {
+                    if constexpr (F32) {
+#pragma unroll
+                        for (int it = 0; it < MAXIT; ++it) {
+                            if (it >= n_iters(pi)) continue;
+                            int r, cj;
+                            unsigned a, b;
+                            item(pi, it, r, cj, a, b);
+                            rres[pi % RING][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)b, soff(pi, p.ldr), 0);
+                        }
+                    }
+                };
+                // phase 2b: residual, activation, bf16, one 16-byte store per item (+ the row statistics of the stored values)
+                auto finish = [&](int pi) {
+#pragma unroll
+                    for (int it = 0; it < MAXIT; ++it) {
+                        if (it >= n_iters(pi)) continue;
+                        int r, cj;
+                        unsigned vo_c, vo_r;
+                        item(pi, it, r, cj, vo_c, vo_r);
+                        u32x4_t packed;
+                        if constexpr (F32) {
+                            float f[8];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                f[e] = __uint_as_float(rd[it][0][e]);
+                                f[4 + e] = __uint_as_float(rd[it][1][e]);
+                            }
+                            if (has_r) {
+                                float g[8];
+                                unpack8(__builtin_bit_cast(bf16x8_raw, rres[pi % RING][it]), g);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += g[e];
+                            }
+                            if constexpr (MODE == 3) {
+                                if (p.epi == 2) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+                                }
+                                if constexpr (XACT) {
+                                    if (p.epi == 3) {
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) f[e] = lrelu02_f(f[e]);
+                                    } else if (p.epi == 4) {
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
+                                    } else if (p.epi == 5) {
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
+                                    }
+                                }
+                            }
+                            packed = __builtin_bit_cast(u32x4_t, pack8(f));
+                        } else {
+                            packed = rd[it][0];
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(packed, rs_c, (int)vo_c, soff(pi, p.ldc), 0);
+                        // The 16 bytes of store data are NOT all sampled when the instruction issues: a VALU write to the first
+                        // data register in the very next slot reached memory in lanes 12..15 of every 16 (measured, tools/
+                        // epi_race_diag.py: the stored dword held the next item's column index).  The compiler's hazard table
+                        // has no wait state for a store with an SGPR offset, so: keep the registers live across a few idle slots.
+                        asm volatile("s_nop 7" ::"v"(packed), "v"(vo_c) : "memory");
+                        if constexpr (FEAT == 3) {   // LayerNorm statistics of the values as STORED (bf16), for the consumer's fold
+                            float g[8], s1 = 0.f, s2 = 0.f;
+                            unpack8(__builtin_bit_cast(bf16x8_raw, packed), g);
+                            const bool live = (int)vo_c >= 0;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float ge = live ? g[e] : 0.f;
+                                s1 += ge;
+                                s2 = __builtin_fmaf(ge, ge, s2);
+                            }
+                            // the lanes that share a row are neighbours: butterfly over them, lane cj == 0 adds the pass's
+                            // partial to the wave's per-row accumulators in LDS (same wave -> ordered)
+                            const int cpo = p_oc(pi) >> 3;
+                            if (cpo >= 2) {
+                                s1 += __shfl_xor(s1, 1);
+                                s2 += __shfl_xor(s2, 1);
+                            }
+                            if (cpo >= 4) {
+                                s1 += __shfl_xor(s1, 2);
+                                s2 += __shfl_xor(s2, 2);
+                            }
+                            if (cpo >= 8) {
+                                s1 += __shfl_xor(s1, 4);
+                                s2 += __shfl_xor(s2, 4);
+                            }
+                            if (cj == 0) {
+                                atomicAdd(rowacc + 2 * r, s1);
+                                atomicAdd(rowacc + 2 * r + 1, s2);
+                            }
+                        }
+                    }
+                };
+
+                if constexpr (FEAT == 3) rowacc[lane_e] = 0.f;
+                if constexpr (F32) {
+                    if (has_r) {
+#pragma unroll
+                        for (int pi = 0; pi < DEPTH && pi < NP; ++pi) load_res(pi);
+                    }
                 }
-                if (FEAT == 3 && p.stats_out) {
-                    // one (sum, sumsq) slot per (row, N tile, wave column): deterministic partials, no global atomics
-                    const int mrow = m0 + wm * TM * 32 + mt * 32 + (lane >> 1);
-                    if (mrow < p.M)
-                        p.stats_out[((bz * p.M + mrow) * (long long)p.stats_p + (bn * WN + wn)) * 2 + (lane & 1)] = rowacc[lane];
+                // Slab hand-overs (write -> read of the same slab, read -> re-write with a single slab) are fenced with
+                // s_waitcnt lgkmcnt(0): a wave's DS ops execute in order, the fence only keeps the COMPILER from moving the slab
+                // accesses (differently typed views of the same bytes) across each other; with two slabs per wave it sits where
+                // the older ops have long completed.
+                auto lds_fence = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+                park(0);
+                lds_fence();
+                fetch(0);
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    if constexpr (F32) {
+                        if (has_r && pi + DEPTH < NP) load_res(pi + DEPTH);
+                    }
+                    if (pi + 1 < NP) {
+                        if constexpr (!DBL) lds_fence();   // one slab: the rows of pass pi must have been read before it is re-used
+                        park(pi + 1);
+                    }
+                    finish(pi);
+                    if constexpr (FEAT == 3) {
+                        if (pi % PP == PP - 1) {
+                            // one (sum, sumsq) slot per (row, N tile, wave column): deterministic partials, no global atomics
+                            const int mrow = m0 + wm * TM * 32 + p_mt(pi) * 32 + (lane_e >> 1);
+                            if (mrow < p.M)
+                                p.stats_out[((bz * p.M + mrow) * (long long)p.stats_p + (bn * WN + wn)) * 2 + (lane_e & 1)] = rowacc[lane_e];
+                            rowacc[lane_e] = 0.f;
+                        }
+                    }
+                    if (pi + 1 < NP) {
+                        lds_fence();                       // (the values parked before finish(pi) have landed by now)
+                        fetch(pi + 1);
+                    }
+                    // (keep the scheduler from hoisting later passes' conversions up here: with 160 live accumulators that spills)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            if (CONV && p.mode == 4) run(std::integral_constant<int, CONV ? 4 : 0>{});   // (host: no residual / GEGLU with mode 4)
+            else if (p.epi == 0 && !R) run(std::integral_constant<int, 0>{});
+            else if (p.epi == 0) run(std::integral_constant<int, 1>{});
+            else if (geglu && !R) run(std::integral_constant<int, 2>{});
+            else if constexpr (XACT) run(std::integral_constant<int, 3>{});
             return;
         }
     }
@@ -895,8 +1044,11 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             for (int b = 0; b < TM; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        SDV_STAMP(1);
         kloop();
+        SDV_STAMP(2);
         epilogue();
+        SDV_STAMP(4);
         if (!has_next) break;
         vb += (int)gridDim.x;
         slot0 = (slot0 + nkt) & 1;
@@ -921,11 +1073,10 @@ template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT =
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int TILE_BYTES = (BM + BN) * BK * (FEAT == 8 ? 1 : 2);
-    constexpr int SLABS = WM * WN * 32 * 64 * 4;                       // fp32 staging slabs of the epilogue
-    constexpr int VECS = WM * WN * 256 + 3 * BN * 4;                   // row-stat accumulators + column vectors
-    constexpr bool PERSIST = WM * WN == 8 && NST == 2;                 // (see the kernel: slabs alias ONE K-slab slot)
-    constexpr int SLOT = TILE_BYTES > SLABS ? TILE_BYTES : SLABS;
-    constexpr int LDS = PERSIST ? 2 * SLOT + VECS : (NST * TILE_BYTES > SLABS + VECS ? NST * TILE_BYTES : SLABS + VECS);
+    constexpr bool PERSIST = WM * WN == 8 && NST == 2;                 // (see the kernel)
+    constexpr int SLABS = 2 * WM * WN * 32 * 144;                      // the epilogue's staging slabs (alias ONE K-slab buffer)
+    constexpr int SLOT = PERSIST && SLABS > TILE_BYTES ? SLABS : TILE_BYTES;
+    constexpr int LDS = NST * SLOT + 3 * BN * 4 + WM * WN * 256;       // K-slab buffers + column vectors + row-stat accumulators
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
@@ -942,7 +1093,10 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     return SDV_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int NST = 2, bool LN_OK = false>
+// LN_OK: the tile carries the LayerNorm-fold / row-statistics / fp8 variants; LN2_OK: also the column-side fold (the 256 x 320
+// tile does not: with 160 accumulators its epilogue spilled 276 bytes per lane, and the V^T projections it exists for -
+// M = channels - never pick that tile)
+template <int WM, int WN, int TM, int TN, int BK, int NST = 2, bool LN_OK = false, bool LN2_OK = LN_OK>
 int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
     if (a.fp8) {
         if constexpr (LN_OK) {   // the same four 8-wave / 4-wave tiles carry the fp8 variants
@@ -955,10 +1109,12 @@ int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
     if (a.ln_side || a.stats_out) {
         if constexpr (LN_OK) {
             if (a.mode == 0 && a.ln_side == 1 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 1>(a, stream);
-            if (a.mode == 0 && a.ln_side == 2 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 2>(a, stream);
+            if constexpr (LN2_OK) {
+                if (a.mode == 0 && a.ln_side == 2 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 2>(a, stream);
+            }
             if (a.mode == 0 && a.ln_side == 0) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 3>(a, stream);
         }
-        SDV_REQUIRE(false, "sdv_gemm_bf16: the LayerNorm fold / row statistics exist for dense GEMMs on tiles 1, 6, 7, 9 only (and not combined)");
+        SDV_REQUIRE(false, "sdv_gemm_bf16: the LayerNorm fold / row statistics exist for dense GEMMs on tiles 1, 6, 7, 9 only (not combined; column-side fold: 1, 7, 9)");
     }
     return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST>(a, stream)
                        : launch_igemm_t<WM, WN, TM, TN, BK, true, NST>(a, stream);
@@ -976,6 +1132,13 @@ extern "C" int sdv_gemm_stats_slots(const sdv_gemm_args* args) { return sdv_gemm
 
 // 1 (default): the 8-wave tiles run as persistent workgroups (one per CU, walking tiles); 0: one workgroup per tile.  Returns
 // the previous setting.  Results are identical either way; this exists so tools/ can time both on the same box.
+#ifdef SDV_GEMM_TIMING
+extern "C" int sdv_gemm_debug_timing(void* buf) {
+    long long* b = (long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf), &b, sizeof(b));
+}
+#endif
+
 extern "C" int sdv_gemm_set_persistent(int on) {
     const int prev = g_persistent;
     g_persistent = on ? 1 : 0;
@@ -1073,6 +1236,7 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         for (const Cand& c : cands) {
             if (a.epi >= 3 && c.id >= 6) continue;   // extended activations exist in the 4-wave tiles only
             if ((a.ln_side || a.stats_out || a.fp8) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9)) continue;   // LN fold / fp8 tiles
+            if (a.ln_side == 2 && c.id == 6) continue;                                                                   // (no column-side fold there)
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
             const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {
@@ -1091,15 +1255,16 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     }
     if (plan_only) return a.stats_p;
     SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
+    SDV_REQUIRE(!(a.epi == 1 && a.R), "sdv_gemm_bf16: GEGLU does not take a residual");
     switch (tile) {
 #ifdef SDV_GEMM_ONLY_TILE6   // (tools: compile the 256 x 320 tile alone for resource / ISA inspection)
-        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true>(a, s);
+        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true, false>(a, s);
 #elif !defined(SDV_GEMM_RING_ONLY)   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
         case 1: return launch_igemm<2, 2, 2, 2, 64, 2, true>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
         case 3: return launch_igemm<2, 2, 1, 1, 64>(a, s);    //  64 x  64
         case 4: return launch_igemm<2, 2, 4, 2, 64>(a, s);    // 256 x 128, 4 waves
-        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true>(a, s);    // 256 x 320, 8 waves (UNet widths are multiples of 320)
+        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true, false>(a, s);    // 256 x 320, 8 waves (UNet widths are multiples of 320)
         case 7: return launch_igemm<4, 2, 2, 4, 64, 2, true>(a, s);    // 256 x 256, 8 waves
         case 8: return launch_igemm<4, 2, 2, 2, 64>(a, s);    // 256 x 128, 8 waves
         case 9: return launch_igemm<4, 2, 1, 5, 64, 2, true>(a, s);    // 128 x 320, 8 waves
