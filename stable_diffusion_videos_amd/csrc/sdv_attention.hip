@@ -15,13 +15,7 @@
 // One workgroup = 4 waves x 32 queries = 128 queries of one head; K / V^T tiles of 64 keys are
 // register-staged (global -> VGPR issued before the MFMA phase, VGPR -> LDS after the barrier).
 // Head sizes: dh = 40 (K padded to 48 for QK^T, to 64 rows for PV), 64, 80 (96 rows for PV), 160.
-#include <stdlib.h>
-
 #include "sdv_common.h"
-
-#ifndef SDV_WHATIF
-#define SDV_WHATIF 0
-#endif
 
 namespace {
 
@@ -224,31 +218,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
                 if (t + 2 < ntiles) load_tile((t + 2) * 64);
             }
         } else {
-#if SDV_WHATIF == 2       // timing experiment: what do the two barriers cost?  (racy)
-            store_tile(0);
-            if (t + 1 < ntiles) load_tile((t + 1) * 64);
-#elif SDV_WHATIF == 4     // timing experiment: what does the K / V staging cost?  (one tile reused)
-            if (t == 0) {
-                __syncthreads();
-                store_tile(0);
-                __syncthreads();
-            }
-#elif SDV_WHATIF == 5     // timing experiment: global loads kept, LDS stores skipped after the first tile
-            __syncthreads();
-            if (t == 0) store_tile(0);
-            __syncthreads();
-            if (t + 1 < ntiles) load_tile((t + 1) * 64);
-            if (t + 1 == ntiles) asm volatile("" ::"v"(kreg[0]), "v"(vreg[0]));
-#elif SDV_WHATIF == 6     // timing experiment: LDS stores + barriers kept, global loads skipped after the first tile
-            __syncthreads();
-            store_tile(0);
-            __syncthreads();
-#else
             __syncthreads();  // previous tile fully consumed (and the pad zeroing is visible)
             store_tile(0);
             __syncthreads();
             if (t + 1 < ntiles) load_tile((t + 1) * 64);
-#endif
         }
 
         if constexpr (PP) {
@@ -272,9 +245,6 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
             };
             auto tile_max = [&](const f32x16_t& a, const f32x16_t& b) {
                 float mx = a[0];
-#if SDV_WHATIF == 3   // timing experiment: what does the row max cost?  (wrong results)
-                return fmaxf(mx, b[3]);
-#endif
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, a[r]);
 #pragma unroll
@@ -308,11 +278,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
                 u32x4_t pr;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-#if SDV_WHATIF == 1   // timing experiment (tools/ubench/build_whatif.py): what do the exps cost?  (wrong results)
-                    pr[e] = pack_bf16x2(a[8 * u + 2 * e] * 0.5f, a[8 * u + 2 * e + 1] * 0.5f);
-#else
                     pr[e] = pack_bf16x2(__builtin_amdgcn_exp2f(a[8 * u + 2 * e]), __builtin_amdgcn_exp2f(a[8 * u + 2 * e + 1]));
-#endif
                 return __builtin_bit_cast(bf16x8_t, pr);
             };
             // P quarter ju = (key half j, register half u) feeds both d-tiles straight away: the v_exp_f32 stream (the
@@ -504,43 +470,25 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
     using Cfg = AttnCfg<DH>;
     const int nqb = (Lq + 128 * QT - 1) / (128 * QT);
     dim3 grid(nqb * (((B * H + 7) / 8) * 8));             // 1-D over (head group, query block, XCD slot)
-    // experiment knob, default OFF: one barrier per tile measured -4 % at dh = 40 (8 more VGPRs -> 3 waves / SIMD) and
-    // +-0 at dh = 80; the two barriers are not what limits this kernel.
-    static const bool dbuf_env = getenv("SDV_ATTN_DBUF") && atoi(getenv("SDV_ATTN_DBUF")) != 0;
-    const bool dbuf = dbuf_env && DH <= 80;   // dh = 160: two buffers would cost a resident workgroup (2 x 89 KB > 160 KB)
-    const int lds = (Cfg::K_BYTES + Cfg::V_BYTES) * (dbuf ? 2 : 1);
-    static const bool prio = !(getenv("SDV_ATTN_PRIO") && atoi(getenv("SDV_ATTN_PRIO")) == 0);   // default on (+1..3 %)
-    static const bool lean_env = !(getenv("SDV_ATTN_LEAN") && atoi(getenv("SDV_ATTN_LEAN")) == 0);
-    const bool lean = lean_env && (DH % 32 != 0);   // dh = 64 / 160 have no padding rows or columns to exploit
+    // Variants measured and not shipped (the template flags remain so that a tools build can instantiate them): one barrier per
+    // tile with two K / V^T buffers (DBUF) -4 % at dh = 40 (8 more VGPRs -> 3 waves / SIMD), +-0 at dh = 80; no s_setprio
+    // around the MFMA blocks (PRIO = false) -1..3 %; 8 waves per workgroup (NW = 8, one staged tile serves 512 queries) +-0.
+    const int lds = Cfg::K_BYTES + Cfg::V_BYTES;
+    constexpr bool lean = DH % 32 != 0;   // dh = 64 / 160 have no padding rows or columns to move softmax work into
     const float sl = scale * 1.4426950408889634f;   // (the caller passes 1 / log2(e) for a pre-scaled Q: sl == 1, the
                                                     //  kernels' own Q scaling then reproduces the bf16 values bit for bit)
 #define SDV_ATTN_LAUNCH(P, L, D) \
     hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, \
                        causal, B * H)
-    if constexpr (DH == 40 && QT == 2) {
-        // software-pipelined two-query-tile kernel: full key tiles only, no mask (the 64^2 self-attention)
-        static const bool pp_env = !(getenv("SDV_ATTN_PP") && atoi(getenv("SDV_ATTN_PP")) == 0);
-        if (pp_env && prio && lean && !dbuf && !causal && Lk % 64 == 0) {
-            // experiment knob, default OFF: 8 waves per workgroup (one staged K / V^T tile serves 512 queries instead of
-            // 256) measured +-0 against 4 waves - halving the staging traffic per query does not buy anything
-            static const bool w8 = getenv("SDV_ATTN_NW") && atoi(getenv("SDV_ATTN_NW")) == 8;
-            if (w8) {
-                const int nqb8 = (Lq + 511) / 512;
-                hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true, 8>), dim3(nqb8 * (((B * H + 7) / 8) * 8)),
-                                   dim3(512), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, causal, B * H);
-            } else {
-                hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq,
-                                   Lk, ldq, ldk, ldv, ldo, sl, causal, B * H);
-            }
-            SDV_CHECK_LAUNCH("sdv_attention_bf16");
-            return SDV_OK;
-        }
+    if constexpr (QT == 2) {
+        // software-pipelined two-query-tile kernel: dh = 40, full key tiles only, no mask (the 64^2 self-attention; the caller
+        // checks).  Two tiles per wave WITHOUT the pipelined body measured -3 % .. +1 % and are not compiled.
+        static_assert(DH == 40, "two query tiles per wave exist for dh = 40 only");
+        hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq,
+                           ldk, ldv, ldo, sl, causal, B * H);
+    } else {
+        SDV_ATTN_LAUNCH(true, lean, false);
     }
-    if (!prio) SDV_ATTN_LAUNCH(false, false, false);      // reference variant kept for A/B runs (SDV_ATTN_PRIO=0)
-    else if (lean && dbuf) SDV_ATTN_LAUNCH(true, true, true);
-    else if (lean) SDV_ATTN_LAUNCH(true, true, false);
-    else if (dbuf) SDV_ATTN_LAUNCH(true, false, true);
-    else SDV_ATTN_LAUNCH(true, false, false);
 #undef SDV_ATTN_LAUNCH
     SDV_CHECK_LAUNCH("sdv_attention_bf16");
     return SDV_OK;
@@ -549,14 +497,11 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
 template <int DH>
 int launch_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
                      int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
-    // Two 32-query tiles per wave (halves the LDS fragment traffic and barriers per MFMA, 2 waves / SIMD).  Plain QT = 2
-    // measured -3 % .. +1 %; with the software-pipelined body (PP: dh = 40, full key tiles, no mask - the 64^2
-    // self-attention) +5.5 %, so that combination is the default.  SDV_ATTN_QT=1 / 2 force either form.
-    static const int qt_env = getenv("SDV_ATTN_QT") ? atoi(getenv("SDV_ATTN_QT")) : 0;
-    if constexpr (DH <= 64) {
-        const bool pp_ok = DH == 40 && !causal && Lk % 64 == 0;
-        const bool two = qt_env ? qt_env == 2 : pp_ok;
-        if (two && Lq >= 1024) return launch_attention_q<DH, 2>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+    // Two 32-query tiles per wave (halves the LDS fragment traffic and barriers per MFMA, 2 waves / SIMD) with the
+    // software-pipelined body: +5.5 % on the 64^2 self-attention (dh = 40, full key tiles, no mask).
+    if constexpr (DH == 40) {
+        const bool pp_ok = !causal && Lk % 64 == 0;
+        if (pp_ok && Lq >= 1024) return launch_attention_q<DH, 2>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
     }
     return launch_attention_q<DH, 1>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
 }
