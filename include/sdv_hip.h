@@ -102,6 +102,16 @@ typedef struct sdv_gemm_args {
      * (its dtype is whatever torch_dtype says, stable_diffusion_pipeline.py:840-858); here the ResBlock convolutions take fp8
      * activations written by sdv_groupnorm_apply(Y8, q_scale) and fp8 weights.  Tiles 1 / 6 / 7 / 9. */
     int32_t fp8;
+    /* out_mode != 0: the output leaves in another type than bf16 (C may then be NULL), N <= 32, 4-wave tiles only (auto: 256x32):
+     *   1  out_f32 [M][ldc] fp32                                    (UNet conv_out 320 -> 4: the noise prediction stays fp32)
+     *   2  image epilogue of the VAE's conv_out 128 -> 3 (stable_diffusion_pipeline.py:432-438 + numpy_to_pil :450):
+     *      v = clamp(v / 2 + 0.5, 0, 1) -> out_f32 [M][ldc] (optional) and out_u8 [M][ldc] = round-half-even(255 v) (optional)
+     *   3  as 2 with v = clamp(v, 0, 1)            (RRDBNet conv_last of the Real-ESRGAN upsampler, upsampling.py:25-28)
+     * so that the two Cout <= 4 convolutions run on the matrix cores (N padded to one 32-column MFMA tile) instead of
+     * sdv_conv3x3_cout_small's one-wave-per-pixel reduction. */
+    int32_t out_mode;
+    float* out_f32;
+    uint8_t* out_u8;
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);

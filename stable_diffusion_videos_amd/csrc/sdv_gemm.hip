@@ -561,7 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                              (((p.sC | p.sR) & 7) == 0);
         // (the 8-wave tiles compile the three common store sequences only: SiLU - the one extra activation they offer, used
         //  by no network here - takes the register-direct path below; the 4-wave tiles carry the generic sequence as well)
-        if (aligned && (XACT || p.epi == 0 || (geglu && !R))) {
+        if (aligned && !p.out_mode && (XACT || p.epi == 0 || (geglu && !R))) {
             // Staged stores: the MFMA leaves lane (l31, lhi) with row l31 and, per accumulator quad, 4 consecutive columns -
             // stored as they are, every 16-byte piece of a wave's store instruction lies in a different row, and the texture
             // addresser takes them one by one (measured: 9.5k clocks for the 160 stores of a 256 x 320 tile, the whole K loop
@@ -978,6 +978,24 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     v[e] = acc[nt][mt][4 * g4 + e] * (nb < acols ? alpha : 1.f) + bm_;
                     if (bias && p.bias_mode == 1 && nb + e < p.N) v[e] += bias[nb + e];
                 }
+                if constexpr (XACT) {
+                    if (p.out_mode) {   // fp32 / image output of the Cout <= 4 convolutions (sdv_hip.h "out_mode")
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (nb + e >= p.N) continue;
+                            const long long idx = (long long)m * p.ldc + nb + e;
+                            float t = v[e];
+                            if (p.out_mode == 1) {
+                                p.out_f32[idx] = t;
+                            } else {
+                                t = fminf(fmaxf(p.out_mode == 2 ? t * 0.5f + 0.5f : t, 0.f), 1.f);
+                                if (p.out_f32) p.out_f32[idx] = t;
+                                if (p.out_u8) p.out_u8[idx] = (uint8_t)rintf(t * 255.0f);
+                            }
+                        }
+                        continue;
+                    }
+                }
                 if (vec_ok && nb + 3 < p.N) {
                     if (R) {
                         const uint2 r = *(const uint2*)(R + (long long)m * p.ldr + nb);
@@ -1148,7 +1166,15 @@ extern "C" int sdv_gemm_set_persistent(int on) {
 static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only) {
     SDV_REQUIRE(args != nullptr, "sdv_gemm_bf16: null args");
     sdv_gemm_args a = *args;
-    SDV_REQUIRE(a.X && a.W && a.C, "sdv_gemm_bf16: null operand");
+    SDV_REQUIRE(a.X && a.W && (a.C || a.out_mode), "sdv_gemm_bf16: null operand");
+    SDV_REQUIRE(a.out_mode >= 0 && a.out_mode <= 3, "sdv_gemm_bf16: bad out_mode %d", a.out_mode);
+    if (a.out_mode) {
+        SDV_REQUIRE(a.N <= 32 && a.ldc >= a.N && !a.R && a.epi == 0 && !a.ln_side && !a.stats_out && a.mode != 4 && a.batch <= 1,
+                    "sdv_gemm_bf16: out_mode is the plain N <= 32 output form (no residual / activation / fold / batch)");
+        SDV_REQUIRE(a.out_mode == 1 ? a.out_f32 != nullptr : (a.out_f32 || a.out_u8), "sdv_gemm_bf16: out_mode %d without an output", a.out_mode);
+        SDV_REQUIRE(a.tile == 0 || (a.tile >= 1 && a.tile <= 4) || a.tile == 10 || a.tile == 11, "sdv_gemm_bf16: out_mode exists in the 4-wave tiles only");
+        if (a.tile == 0) a.tile = 10;   // 256 x 32: one 32-column MFMA tile holds all the outputs
+    }
     SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SDV_REQUIRE(a.K % 64 == 0, "sdv_gemm_bf16: K=%d must be a multiple of 64", a.K);
     SDV_REQUIRE(a.mode >= 0 && a.mode <= 4, "sdv_gemm_bf16: bad mode %d", a.mode);

@@ -432,8 +432,9 @@ class UNetEngine:
                 hh, ww = 2 * hh, 2 * ww
         h = hip.groupnorm(h, self.out_g, self.out_b, nimg=nimg, HW=hh * ww, groups=self.groups, eps=self.eps, silu=True)
         eps = torch.empty((nimg, hh, ww, self.cfg.out_channels), dtype=F32, device=self.device)
-        hip.conv3x3_cout_small(h, self.conv_out_w, self.conv_out_b, nimg=nimg, H=hh, W=ww, out_mode=0, out_f32=eps,
-                               circular=circ)
+        # conv_out 320 -> 4 on the matrix cores (one 32-column MFMA tile, fp32 straight from the accumulators)
+        hip.conv3x3(h, self.conv_out_w, self.conv_out_b, nimg=nimg, H=hh, W=ww, circular=circ, out_mode=1,
+                    out_f32=eps.view(-1, self.cfg.out_channels))
         return eps
 
 
@@ -513,6 +514,7 @@ class VAEDecoderEngine:
         oc = self.cfg.out_channels
         u8 = torch.empty((B, h, w, oc), dtype=torch.uint8, device=self.device)
         f32 = torch.empty((B, h, w, oc), dtype=F32, device=self.device) if want_float else None
-        hip.conv3x3_cout_small(x, self.conv_out_w, self.conv_out_b, nimg=B, H=h, W=w, out_mode=1, out_f32=f32,
-                               out_u8=u8, circular=circ)
+        # conv_out 128 -> 3 on the matrix cores with the image epilogue (clamp(v / 2 + 0.5) -> round-half-even uint8)
+        hip.conv3x3(x, self.conv_out_w, self.conv_out_b, nimg=B, H=h, W=w, circular=circ, out_mode=2,
+                    out_f32=f32.view(-1, oc) if f32 is not None else None, out_u8=u8.view(-1, oc))
         return u8, f32

@@ -11,7 +11,7 @@ Data layout in HBM (per chunk of n frames, M = n*H*W low-resolution pixels):
     next buffer.  Prefix widths 96 / 160 are read as 128 / 192 against zero-padded weights (K granularity 64).
   * the trunk feature, the two up-sampled tensors ([16 M, 64] at 4x) and the uint8 output frames.
 Every conv is ``sdv_gemm_bf16`` in implicit-GEMM conv mode with the LeakyReLU(0.2) epilogue (epi 3); conv_first is
-im2col(4 channels) + K = 64 GEMM; conv_last is ``sdv_conv3x3_cout_small`` with the clamp / round / uint8 epilogue.
+im2col(4 channels) + K = 64 GEMM; conv_last is the same igemm with its image epilogue (``out_mode`` 3: clamp / round / uint8).
 """
 from __future__ import annotations
 
@@ -104,7 +104,8 @@ class RRDBNetEngine:
         w, b = self.tail["conv_last"]
         u8 = torch.empty((n, 4 * H, 4 * W, 3), dtype=torch.uint8, device=self.device)
         f32 = torch.empty((n, 4 * H, 4 * W, 3), dtype=F32, device=self.device) if want_float else None
-        hip.conv3x3_cout_small(hr, w, b, nimg=n, H=4 * H, W=4 * W, out_mode=2, out_f32=f32, out_u8=u8)
+        hip.conv3x3(hr, w, b, nimg=n, H=4 * H, W=4 * W, out_mode=3, out_f32=f32.view(-1, 3) if f32 is not None else None,
+                    out_u8=u8.view(-1, 3) if u8 is not None else None)
         return u8, f32
 
     @torch.no_grad()

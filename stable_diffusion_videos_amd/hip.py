@@ -37,11 +37,11 @@ class GemmArgs(C.Structure):
         ("div_hw_mul", C.c_uint32), ("div_hw_shr", C.c_uint32), ("div_w_mul", C.c_uint32), ("div_w_shr", C.c_uint32),
         ("alpha_cols", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
-        ("fp8", C.c_int32),
+        ("fp8", C.c_int32), ("out_mode", C.c_int32), ("out_f32", C.c_void_p), ("out_u8", C.c_void_p),
     ]
 
 
-ABI_VERSION = 4     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 5     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -169,8 +169,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          circular: bool = False, batch: int = 1, sX: int = 0, sW: int = 0, sC: int = 0, sR: int = 0,
          step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
          x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None, ln_side: int = 1,
-         want_stats: bool = False, ln_eps: float = 1e-5):
+         want_stats: bool = False, ln_eps: float = 1e-5, out_mode: int = 0, out_f32: Optional[torch.Tensor] = None,
+         out_u8: Optional[torch.Tensor] = None):
     """Raw wrapper of ``sdv_gemm_bf16`` (element offsets x_off / w_off / out_off select sub-matrices).
+    ``out_mode`` 1 / 2: fp32 output / image epilogue into ``out_f32`` / ``out_u8`` (``out`` may be None), see sdv_hip.h.
     ``ln=(stats, s)``: LayerNorm folded into this GEMM (sdv_hip.h): ``stats`` fp32 [rows, 2] = (mean, rstd) from
     ``want_stats`` of the producer, ``s`` fp32 row sums of the gamma-scaled weights.  ``want_stats=True`` returns the
     (mean, rstd) [batch*M, 2] of this GEMM's OUTPUT rows over its N columns (for the next LayerNorm)."""
@@ -188,7 +190,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
         a.W = _ptr(w, BF16, "W") + 2 * w_off
     a.bias = _ptr(bias, F32, "bias")
     a.R = _ptr(residual, BF16, "R")
-    a.C = _ptr(out, BF16, "C") + 2 * out_off
+    a.C = _ptr(out, BF16, "C") + 2 * out_off if out is not None else None
+    a.out_mode, a.out_f32, a.out_u8 = out_mode, _ptr(out_f32, F32, "out_f32"), _ptr(out_u8, torch.uint8, "out_u8")
     a.step_ptr = _ptr(step_ptr, torch.int32, "step_ptr")
     a.zero_page = zero_page(x.device).data_ptr()
     a.sX, a.sW, a.sC, a.sR = sX, sW, sC, sR
@@ -249,10 +252,12 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, nimg: int, H: int, W: int,
             mode: int = 1, x2: Optional[torch.Tensor] = None, residual=None, circular: bool = False,
             step_ptr=None, bias_step_stride: int = 0, out=None, tile: int = 0, epi: int = 0,
-            alpha: float = 1.0) -> torch.Tensor:
+            alpha: float = 1.0, out_mode: int = 0, out_f32=None, out_u8=None) -> torch.Tensor:
     """NHWC conv3x3 pad 1.  x: [nimg*H*W, C1] (+ x2 [.., C2]); w: [Cout, 9*(C1+C2)] (OHWI).
     mode 1: stride 1; 2: stride 2; 3: nearest-2x upsample then conv.  x / out / residual may be column
-    slices of wider row-major buffers (row stride = .stride(0)): dense-block concat without copies."""
+    slices of wider row-major buffers (row stride = .stride(0)): dense-block concat without copies.
+    ``out_mode`` 1: fp32 result in ``out_f32`` [M, Cout]; 2: image epilogue (clamp(v/2+0.5), fp32 in ``out_f32`` and / or
+    uint8 in ``out_u8``) - the Cout <= 4 output convolutions of the UNet / VAE on the matrix cores; nothing is returned."""
     C1 = x.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     Cout = w.shape[0]
@@ -267,13 +272,19 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
     else:
         Ho, Wo = 2 * H, 2 * W
     M = nimg * Ho * Wo
-    if out is None:
-        out = torch.empty((M, Cout), dtype=BF16, device=x.device)
-    gemm(x, w, out, M=M, N=Cout, K=C1 + C2, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
+    if out_mode:
+        if (out_f32 is None and out_u8 is None) or out is not None or residual is not None:
+            raise SdvHipError("conv3x3: out_mode needs out_f32 / out_u8 (and takes no bf16 output / residual)")
+        ldc = Cout
+    else:
+        if out is None:
+            out = torch.empty((M, Cout), dtype=BF16, device=x.device)
+        ldc = out.stride(0)
+    gemm(x, w, out, M=M, N=Cout, K=C1 + C2, ldx=x.stride(0), ldw=w.stride(0), ldc=ldc, bias=bias,
          residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2,
          C1=C1 if x2 is not None else 0, ldx2=x2.stride(0) if x2 is not None else 0, mode=mode, Hin=H, Win=W,
          Hout=Ho, Wout=Wo, circular=circular, step_ptr=step_ptr, bias_step_stride=bias_step_stride, tile=tile,
-         epi=epi, alpha=alpha)
+         epi=epi, alpha=alpha, out_mode=out_mode, out_f32=out_f32, out_u8=out_u8)
     return out
 
 

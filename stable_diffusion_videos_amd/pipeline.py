@@ -394,12 +394,14 @@ class StableDiffusionWalkPipeline:
         sched_key, coefs, nsteps = self._schedule(num_inference_steps, eta)                       # :394
         # A ragged last batch (B frames where a graph for B' > B frames is already captured) is padded with copies of its
         # last frame and replays the big graph: a second capture would own a second multi-GB private pool for one call.
+        # Only while the padding is at most a quarter of the big batch - 60 frames replayed as 128 would pay for 128.
         B_real = B
         if self.use_graphs and eta == 0 and callback is None:
             tail = (h, w, do_cfg, float(guidance_scale), False, int(ctx.shape[1]), self.cfg_shared_prefix, self.tiled)
             mult = 2 if do_cfg else 1
             bigger = [k[1] // mult for k in self._graphs if k[0] == sched_key and k[2:] == tail and k[1] // mult > B]
-            if bigger and (B * mult, ) + tail not in {k[1:] for k in self._graphs if k[0] == sched_key}:
+            if bigger and 4 * (min(bigger) - B) <= min(bigger) and \
+                    (B * mult, ) + tail not in {k[1:] for k in self._graphs if k[0] == sched_key}:
                 pad = min(bigger) - B
                 latents = torch.cat([latents, latents[-1:].expand(pad, -1, -1, -1)])
                 if do_cfg:

@@ -323,6 +323,11 @@ def test_conv_small_channel_kernels(hip, dev):
         hip.conv3x3_cout_small(x.reshape(-1, 320).to(BF16), conv_w(w, dev), b, nimg=n, H=H, W=W, out_mode=0, out_f32=o,
                                circular=circular)
         assert rel_l2(o, conv_ref(x, w, b, 1, circular)) < 1e-5
+        # the same conv on the matrix cores (what UNetEngine runs): N = 4 in one 32-column MFMA tile, fp32 from the accumulators
+        o2 = torch.empty((n * H * W, 4), dtype=F32, device=dev)
+        hip.conv3x3(x.reshape(-1, 320).to(BF16), conv_w(w, dev), b, nimg=n, H=H, W=W, circular=circular, out_mode=1, out_f32=o2)
+        assert rel_l2(o2.view_as(o), conv_ref(x, w, b, 1, circular)) < 1e-5
+        assert float((o2.view_as(o) - o).abs().max()) < 1e-4
     # 128 -> 3 with the image epilogue (VAE conv_out): clamp(v/2+0.5) and round-half-even uint8
     x, w, b = rnd((n, H, W, 128), dev, 36), rnd((3, 128, 3, 3), dev, 37, 2 * (9 * 128) ** -0.5), rnd((3,), dev, 38)
     f = torch.empty((n, H, W, 3), dtype=F32, device=dev)
@@ -331,6 +336,16 @@ def test_conv_small_channel_kernels(hip, dev):
     ref = (conv_ref(x, w, b, 1, False) / 2 + 0.5).clamp(0, 1)
     assert float((f - ref).abs().max()) < 1e-5
     assert torch.equal(u.cpu(), torch.from_numpy((f.cpu().numpy() * 255).round().astype("uint8")))
+    # ... and through the igemm's image epilogue (what VAEDecoderEngine runs), every 4-wave tile
+    for tile in (0, 1, 2, 3, 10, 11):
+        f2 = torch.empty((n * H * W, 3), dtype=F32, device=dev)
+        u2 = torch.zeros((n * H * W, 3), dtype=torch.uint8, device=dev)
+        hip.conv3x3(x.reshape(-1, 128).to(BF16), conv_w(w, dev), b, nimg=n, H=H, W=W, out_mode=2, out_f32=f2, out_u8=u2, tile=tile)
+        assert float((f2.view_as(ref) - ref).abs().max()) < 1e-5, tile
+        assert torch.equal(u2.cpu(), torch.from_numpy((f2.cpu().numpy() * 255).round().astype("uint8")))
+        assert int((u2.view_as(u).int() - u.int()).abs().max()) <= 1          # (two fp32 summation orders: ties may flip)
+    with pytest.raises(hip.SdvHipError):      # the 8-wave tiles do not carry the typed outputs
+        hip.conv3x3(x.reshape(-1, 128).to(BF16), conv_w(w, dev), b, nimg=n, H=H, W=W, out_mode=2, out_u8=u2, tile=6)
 
 
 @pytest.mark.parametrize("tile", [0, 2, 3, 10, 11])

@@ -498,18 +498,22 @@ def test_rccl_weight_broadcast_path_runs_with_one_rank(hip, dev, tmp_path):
 
 
 def test_ragged_last_batch_reuses_the_captured_graph(hip, dev, tmp_path):
-    """5 frames at batch_size 4: the 1-frame tail is padded and replays the 4-frame graph (one captured step, one private
-    pool) and still writes the frames a batch_size-1 walk writes."""
+    """7 frames at batch_size 4: the 3-frame tail is padded and replays the 4-frame graph (one captured step, one private
+    pool) and still writes the frames a batch_size-1 walk writes.  A tail that would be MOSTLY padding (1 frame of 4 - or the
+    literal 60-frame config on a 128-frame graph) gets its own graph instead of paying for the big batch."""
     from PIL import Image
     pipe = _tiny_pipeline(dev)
     kw = dict(output_dir=str(tmp_path), fps=3, num_inference_steps=3, height=64, width=64, make_video=False)
-    pipe.walk(["a cat", "a dog"], seeds=[1, 2], num_interpolation_steps=5, name="b4", batch_size=4, **kw)
+    pipe.walk(["a cat", "a dog"], seeds=[1, 2], num_interpolation_steps=7, name="b4", batch_size=4, **kw)
     assert len(pipe._graphs) == 1
-    pipe.walk(["a cat", "a dog"], seeds=[1, 2], num_interpolation_steps=5, name="b1", batch_size=1, **kw)
-    for k in range(5):
+    pipe.walk(["a cat", "a dog"], seeds=[1, 2], num_interpolation_steps=7, name="b1", batch_size=1, **kw)
+    for k in range(7):
         a = np.asarray(Image.open(tmp_path / "b4" / "b4_000000" / f"frame{k:06d}.png")).astype(int)
         b = np.asarray(Image.open(tmp_path / "b1" / "b1_000000" / f"frame{k:06d}.png")).astype(int)
         assert np.abs(a - b).max() <= 2, k
+    pipe2 = _tiny_pipeline(dev)
+    pipe2.walk(["a cat", "a dog"], seeds=[1, 2], num_interpolation_steps=5, name="c4", batch_size=4, **kw)
+    assert len(pipe2._graphs) == 2                    # 4 frames + a 1-frame tail with its own captured step
 
 
 def test_walk_with_audio_and_video(hip, dev, tmp_path):
