@@ -613,21 +613,30 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     if (ok) ln_row[mt][0] = p.ln_s[mrow];
                 }
             }
-            // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
-            // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
-            if (PERSIST && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             {
+                // (one element per thread - BN <= 512 - so that the global loads are all issued BEFORE the wait below and
+                //  their latency overlaps the tail of the prefetch instead of following it)
+                static_assert(BN <= NWV * 64, "one column vector element per thread");
                 constexpr int lnsd = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
                 const bool col_bias = bias && p.bias_mode == 1;
-                for (int i = tid; i < BN; i += NWV * 64) {
-                    const int n = n0 + i;
-                    vbias[i] = (col_bias && n < p.N) ? bias[n] : 0.f;
-                    if constexpr (lnsd == 1) vaux[i] = n < p.N ? p.ln_s[n] : 0.f;
-                    if constexpr (lnsd == 2) {
-                        float2 st = make_float2(0.f, 1.f);
-                        if (n < p.N) st = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
-                        *(float2*)(vaux + 2 * i) = st;
-                    }
+                const int i = tid, n = n0 + tid;
+                const bool live = i < BN && n < p.N;
+                float vb_ = 0.f, vs_ = 0.f;
+                float2 st = make_float2(0.f, 1.f);
+                if (col_bias && live) vb_ = bias[n];
+                if constexpr (lnsd == 1) {
+                    if (live) vs_ = p.ln_s[n];
+                }
+                if constexpr (lnsd == 2) {
+                    if (live) st = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
+                }
+                // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
+                // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
+                if (PERSIST && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (i < BN) {
+                    vbias[i] = vb_;
+                    if constexpr (lnsd == 1) vaux[i] = vs_;
+                    if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st;
                 }
             }
             SDV_STAMP(5);
