@@ -273,7 +273,11 @@ class StableDiffusionWalkPipeline:
         key = (ts, float(eta), self.scheduler.config.prediction_type)
         if key not in self._sched_cache:
             while len(self._sched_cache) >= 8:
-                self._sched_cache.pop(next(iter(self._sched_cache)))
+                gone = next(iter(self._sched_cache))
+                self._sched_cache.pop(gone)
+                # captured steps bake in the pointers of that schedule's coefficient / time-embedding tables
+                for gk in [k for k in self._graphs if k[0] == gone]:
+                    self._graphs.pop(gk)["graph"] = None
             coefs = self.scheduler.coefficient_table(eta).to(self.device)
             self.unet.prepare_timesteps(ts)
             tables = [r.bias_table for r in self.unet.res]
@@ -597,12 +601,14 @@ class StableDiffusionWalkPipeline:
         # exactly the frames whose file is missing or empty (frames are renamed into place only when complete) - for the
         # reference's own on-disk states this is the same set, except that its :750 quirk (a clip with exactly one missing
         # frame is skipped and stays incomplete) is not reproduced.
-        clips = []
+        clips, all_clips = [], {}
         for i, (prompt_a, prompt_b, seed_a, seed_b, num_step) in enumerate(
                 zip(prompts, prompts[1:], seeds, seeds[1:], num_interpolation_steps)):
             save_path = save_path_root / f"{name}_{i:06d}"
             step_output_filepath = save_path / f"{name}_{i:06d}.mp4"
             todo = list(range(num_step))
+            all_clips[i] = dict(i=i, prompt_a=prompt_a, prompt_b=prompt_b, seed_a=seed_a, seed_b=seed_b, num_step=num_step,
+                                todo=todo, save_path=save_path, mp4=step_output_filepath)
             if resume:
                 if step_output_filepath.exists():
                     print(f"Skipping {save_path} because frames already exist")
@@ -618,14 +624,16 @@ class StableDiffusionWalkPipeline:
                     continue
                 if have:
                     print(f"Resuming {save_path.name}: {len(todo)} of {num_step} frames missing (first {todo[0]})")
-            clips.append(dict(i=i, prompt_a=prompt_a, prompt_b=prompt_b, seed_a=seed_a, seed_b=seed_b,
-                              num_step=num_step, todo=todo, save_path=save_path, mp4=step_output_filepath))
+            all_clips[i]["todo"] = todo
+            clips.append(all_clips[i])
         if world_size > 1:
-            # every rank must shard the SAME work list: rank 0's view of the directory decides
-            todo_lists = parallel.broadcast_object([c["todo"] for c in clips] if rank == 0 else None)
-            if len(todo_lists) == len(clips):
-                for c, t in zip(clips, todo_lists):
-                    c["todo"] = t
+            # every rank must shard the SAME work list: rank 0's view of the directory decides - which clips are still open
+            # AND which of their frames are missing (another rank may list the directory a moment later and see more)
+            work = parallel.broadcast_object([(c["i"], c["todo"]) for c in clips] if rank == 0 else None)
+            clips = []
+            for i, t in work:
+                all_clips[i]["todo"] = list(t)
+                clips.append(all_clips[i])
             parallel.barrier()      # every rank has looked at the directory before anyone writes new frames
         shares = parallel.partition_frame_list([c["todo"] for c in clips], world_size, rank)
 
