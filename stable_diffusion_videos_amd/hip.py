@@ -138,7 +138,6 @@ FP8 = torch.float8_e4m3fn      # OCP e4m3, what gfx950's fp8 MFMA and converters
 FP8_MAX = 448.0
 
 _zero_pages = {}
-_GEGLU_TILE = int(__import__("os").environ.get("SDV_GEGLU_TILE", "0"))
 
 # Optional launch observer used by bench.py's roofline pass: called as hook(kind, info_dict, launch_fn).  The
 # hook must call launch_fn() itself (it may bracket it with HIP events).  None = no overhead.
@@ -238,8 +237,6 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if K != K1 + K2:
         raise SdvHipError(f"linear: K mismatch {K} vs {K1}+{K2}")
     n_out = N // 2 if epi == 1 else N
-    if epi == 1 and tile == 0 and _GEGLU_TILE:
-        tile = _GEGLU_TILE                       # experiment knob (SDV_GEGLU_TILE)
     if out is None:
         out = torch.empty((M, n_out), dtype=BF16, device=x.device)
     st = gemm(x, w, out, M=M, N=N, K=K, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
