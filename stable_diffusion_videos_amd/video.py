@@ -4,9 +4,11 @@ AAC audio track).  SURVEY.md section 8(f) rank 2.
 
 torchvision / pyav / ffmpeg are not installed in this image.  When they are, the reference encoding is used.  When
 they are not, a dependency-free writer produces a standards-conforming ISO-BMFF (.mp4) file with a Motion-JPEG
-video track (sample entry ``mp4v``, MPEG-4 objectTypeIndication 0x6C = JPEG, quality 95) so that ``walk()`` returns
-the same ``{name}.mp4`` paths as the reference; H.264 compression and the audio track need ffmpeg and are skipped
-with a warning in that mode.  Frames are read once each (the reference's pairwise ``torch.cat`` is O(n^2), :91-93).
+video track (sample entry ``mp4v``, MPEG-4 objectTypeIndication 0x6C = JPEG, quality 95) and, when an audio file is
+given, an uncompressed 16-bit PCM audio track of the same ``[audio_offset, audio_offset + audio_duration)`` window
+(sample entry ``ipcm`` + ``pcmC``, ISO/IEC 23003-5) so that ``walk()`` returns the same ``{name}.mp4`` paths as the
+reference and the music video still carries its music; H.264 / AAC COMPRESSION needs ffmpeg and is what that mode
+lacks.  Frames are read once each (the reference's pairwise ``torch.cat`` is O(n^2), :91-93).
 """
 from __future__ import annotations
 
@@ -14,7 +16,7 @@ import io
 import logging
 import struct
 from pathlib import Path
-from typing import List, Union
+from typing import List, Optional, Union
 
 import numpy as np
 import torch
@@ -35,24 +37,36 @@ def _descr(tag: int, payload: bytes) -> bytes:
     return bytes([tag, len(payload)]) + payload
 
 
-def write_mjpeg_mp4(jpegs: List[bytes], width: int, height: int, fps: float, path: Union[str, Path]) -> str:
-    """Minimal ISO base media file: ftyp | mdat (the JPEG frames) | moov (one video track, constant frame rate)."""
+def write_mjpeg_mp4(jpegs: List[bytes], width: int, height: int, fps: float, path: Union[str, Path],
+                    audio: Optional[np.ndarray] = None, sr: int = 44100) -> str:
+    """Minimal ISO base media file: ftyp | mdat (the JPEG frames, then the PCM samples) | moov (a constant-frame-rate video
+    track and, with ``audio`` - mono float samples in [-1, 1] at ``sr`` Hz - a 16-bit little-endian PCM audio track)."""
     n = len(jpegs)
     timescale = 90000
     delta = int(round(timescale / float(fps)))
     duration = n * delta
+    pcm = b""
+    n_audio = 0
+    if audio is not None and len(audio):
+        a16 = np.clip(np.round(np.asarray(audio, dtype=np.float64).reshape(-1) * 32767.0), -32768, 32767).astype("<i2")
+        pcm, n_audio = a16.tobytes(), int(a16.shape[0])
+    a_duration = int(round(n_audio * timescale / float(sr))) if n_audio else 0
+    movie_duration = max(duration, a_duration)
     ftyp = _box(b"ftyp", b"isom" + struct.pack(">I", 0x200) + b"isomiso2mp41")
-    mdat = _box(b"mdat", b"".join(jpegs))
+    video_bytes = b"".join(jpegs)
+    mdat = _box(b"mdat", video_bytes + pcm)
     data_offset = len(ftyp) + 8
     matrix = struct.pack(">9I", 0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000)
-    mvhd = _full(b"mvhd", 0, 0, struct.pack(">IIII", 0, 0, timescale, duration) + struct.pack(">IH", 0x10000, 0x100) +
-                 b"\0" * 10 + matrix + b"\0" * 24 + struct.pack(">I", 2))
+    mvhd = _full(b"mvhd", 0, 0, struct.pack(">IIII", 0, 0, timescale, movie_duration) + struct.pack(">IH", 0x10000, 0x100) +
+                 b"\0" * 10 + matrix + b"\0" * 24 + struct.pack(">I", 3 if n_audio else 2))
+    dinf = _box(b"dinf", _full(b"dref", 0, 0, struct.pack(">I", 1) + _full(b"url ", 0, 1, b"")))
+
+    # ---- video track ----
     tkhd = _full(b"tkhd", 0, 3, struct.pack(">IIIII", 0, 0, 1, 0, duration) + b"\0" * 8 + struct.pack(">HHHH", 0, 0, 0, 0) +
                  matrix + struct.pack(">II", width << 16, height << 16))
     mdhd = _full(b"mdhd", 0, 0, struct.pack(">IIII", 0, 0, timescale, duration) + struct.pack(">HH", 0x55C4, 0))
     hdlr = _full(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"vide") + b"\0" * 12 + b"VideoHandler\0")
     vmhd = _full(b"vmhd", 0, 1, struct.pack(">HHHH", 0, 0, 0, 0))
-    dinf = _box(b"dinf", _full(b"dref", 0, 0, struct.pack(">I", 1) + _full(b"url ", 0, 1, b"")))
     total = sum(len(j) for j in jpegs)
     dec_cfg = _descr(0x04, bytes([0x6C, 0x11]) + struct.pack(">I", max(len(j) for j in jpegs))[1:] +
                      struct.pack(">II", int(total * 8 * fps / max(n, 1)), int(total * 8 * fps / max(n, 1))))
@@ -67,8 +81,27 @@ def write_mjpeg_mp4(jpegs: List[bytes], width: int, height: int, fps: float, pat
     stco = _full(b"stco", 0, 0, struct.pack(">II", 1, data_offset))
     stbl = _box(b"stbl", stsd + stts + stsc + stsz + stco)
     minf = _box(b"minf", vmhd + dinf + stbl)
-    trak = _box(b"trak", tkhd + _box(b"mdia", mdhd + hdlr + minf))
-    moov = _box(b"moov", mvhd + trak)
+    traks = _box(b"trak", tkhd + _box(b"mdia", mdhd + hdlr + minf))
+
+    # ---- audio track: one chunk of n_audio two-byte samples behind the video samples ----
+    if n_audio:
+        a_tkhd = _full(b"tkhd", 0, 3, struct.pack(">IIIII", 0, 0, 2, 0, a_duration) + b"\0" * 8 +
+                       struct.pack(">HHHH", 0, 0, 0x0100, 0) + matrix + struct.pack(">II", 0, 0))
+        a_mdhd = _full(b"mdhd", 0, 0, struct.pack(">IIII", 0, 0, int(sr), n_audio) + struct.pack(">HH", 0x55C4, 0))
+        a_hdlr = _full(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"soun") + b"\0" * 12 + b"SoundHandler\0")
+        smhd = _full(b"smhd", 0, 0, struct.pack(">HH", 0, 0))
+        pcmc = _full(b"pcmC", 0, 0, bytes([1, 16]))                       # format_flags 1 = little endian, 16 bits per sample
+        chnl = _full(b"chnl", 0, 0, bytes([1, 1]) + struct.pack(">Q", 0))  # channel-structured, defined layout 1 = mono
+        ipcm = _box(b"ipcm", b"\0" * 6 + struct.pack(">H", 1) + b"\0" * 8 + struct.pack(">HHHH", 1, 16, 0, 0) +
+                    struct.pack(">I", (int(sr) & 0xFFFF) << 16) + pcmc + chnl)
+        a_stsd = _full(b"stsd", 0, 0, struct.pack(">I", 1) + ipcm)
+        a_stts = _full(b"stts", 0, 0, struct.pack(">III", 1, n_audio, 1))
+        a_stsc = _full(b"stsc", 0, 0, struct.pack(">IIII", 1, 1, n_audio, 1))
+        a_stsz = _full(b"stsz", 0, 0, struct.pack(">II", 2, n_audio))
+        a_stco = _full(b"stco", 0, 0, struct.pack(">II", 1, data_offset + len(video_bytes)))
+        a_stbl = _box(b"stbl", a_stsd + a_stts + a_stsc + a_stsz + a_stco)
+        traks += _box(b"trak", a_tkhd + _box(b"mdia", a_mdhd + a_hdlr + _box(b"minf", smhd + dinf + a_stbl)))
+    moov = _box(b"moov", mvhd + traks)
     Path(path).parent.mkdir(parents=True, exist_ok=True)
     with open(path, "wb") as f:
         f.write(ftyp + mdat + moov)
@@ -109,12 +142,15 @@ def make_video_pyav(frames_or_frame_dir: Union[str, Path, torch.Tensor] = "./ima
             write_video(output_filepath, stack, fps=fps, options={"crf": "10", "pix_fmt": "yuv420p"})
         return output_filepath
     from PIL import Image
+    audio = None
     if audio_filepath:
-        logger.warning("no ffmpeg/pyav in this environment: writing a Motion-JPEG mp4 WITHOUT the audio track")
+        from .audio import load_audio
+        logger.warning("no ffmpeg/pyav in this environment: writing a Motion-JPEG mp4 with an uncompressed PCM audio track")
+        audio, _ = load_audio(audio_filepath, sr=sr, mono=True, offset=audio_offset, duration=audio_duration)
     jpegs = []
     for fr in frames:
         buf = io.BytesIO()
         Image.fromarray(fr).save(buf, format="JPEG", quality=95, subsampling=2)
         jpegs.append(buf.getvalue())
     h, w = frames[0].shape[:2]
-    return write_mjpeg_mp4(jpegs, w, h, fps, output_filepath)
+    return write_mjpeg_mp4(jpegs, w, h, fps, output_filepath, audio=audio, sr=sr)

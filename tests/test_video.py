@@ -64,3 +64,70 @@ def test_mjpeg_mp4_round_trip(tmp_path):
     t = torch.from_numpy(np.stack(frames)).permute(0, 3, 1, 2)
     out2 = make_video_pyav(t, fps=5, output_filepath=tmp_path / "t.mp4")
     assert abs(len(open(out2, "rb").read()) - len(buf)) < 64
+
+
+def traks(buf):
+    lo, hi = find(buf, ("moov",))
+    return [(a, b) for kind, a, b in parse_boxes(buf, lo, hi) if kind == "trak"]
+
+
+def find_in(buf, lo, hi, path):
+    for name in path:
+        kind, lo, hi = next(b for b in parse_boxes(buf, lo, hi) if b[0] == name)
+    return lo, hi
+
+
+def test_mjpeg_mp4_carries_the_audio_window(tmp_path):
+    """make_video_pyav(audio_filepath=..., audio_offset, audio_duration) (utils.py:69-128, called at
+    stable_diffusion_pipeline.py:786-807): the dependency-free writer adds a 16-bit PCM track holding exactly the
+    [offset, offset + duration) window of the file at ``sr`` - re-parsed here and compared sample by sample."""
+    from pathlib import Path
+    from stable_diffusion_videos_amd.audio import load_audio
+    wav = Path(__file__).parent / "samples" / "choice.wav"
+    frames = torch.randint(0, 255, (6, 3, 32, 48), dtype=torch.uint8, generator=torch.Generator().manual_seed(0))
+    sr, off, dur, fps = 44100, 1.5, 2.0, 3
+    out = make_video_pyav(frames, audio_filepath=str(wav), fps=fps, audio_offset=off, audio_duration=dur, sr=sr,
+                          output_filepath=tmp_path / "a.mp4")
+    buf = open(out, "rb").read()
+    tk = traks(buf)
+    assert len(tk) == 2
+    # movie header: 90 kHz timescale, duration = the longer track (6 frames at 3 fps = 2 s = the audio window)
+    lo, hi = find(buf, ("moov", "mvhd"))
+    _, _, _, timescale, duration = struct.unpack(">IIIII", buf[lo:lo + 20])
+    assert timescale == 90000 and duration == 180000
+    assert struct.unpack(">I", buf[hi - 4:hi])[0] == 3                    # next_track_ID
+    # handler types
+    kinds = []
+    for a, b in tk:
+        lo, hi = find_in(buf, a, b, ("mdia", "hdlr"))
+        kinds.append(buf[lo + 8:lo + 12])
+    assert kinds == [b"vide", b"soun"]
+    a, b = tk[1]
+    lo, hi = find_in(buf, a, b, ("mdia", "mdhd"))
+    _, _, _, a_timescale, a_duration = struct.unpack(">IIIII", buf[lo:lo + 20])
+    assert a_timescale == sr and a_duration == int(sr * dur)
+    stbl = ("mdia", "minf", "stbl")
+    lo, hi = find_in(buf, a, b, stbl + ("stsd",))
+    entry = parse_boxes(buf, lo + 8, hi)[0]
+    assert entry[0] == "ipcm"
+    channels, bits = struct.unpack(">HH", buf[entry[1] + 16:entry[1] + 20])
+    assert (channels, bits) == (1, 16)
+    assert struct.unpack(">I", buf[entry[1] + 24:entry[1] + 28])[0] == sr << 16
+    sub = {k: (x, y) for k, x, y in parse_boxes(buf, entry[1] + 28, entry[2])}
+    assert set(sub) == {"pcmC", "chnl"} and buf[sub["pcmC"][0] + 4:sub["pcmC"][0] + 6] == bytes([1, 16])
+    lo, hi = find_in(buf, a, b, stbl + ("stsz",))
+    _, sample_size, count = struct.unpack(">III", buf[lo:lo + 12])
+    assert (sample_size, count) == (2, int(sr * dur))
+    lo, hi = find_in(buf, a, b, stbl + ("stco",))
+    offset = struct.unpack(">III", buf[lo:lo + 12])[2]
+    mdat = next(x for x in parse_boxes(buf) if x[0] == "mdat")
+    assert mdat[1] < offset and offset + 2 * count == mdat[2]            # the PCM samples close the mdat box
+    pcm = np.frombuffer(buf[offset:offset + 2 * count], dtype="<i2").astype(np.float64) / 32767.0
+    ref, _ = load_audio(wav, sr=sr, mono=True, offset=off, duration=dur)
+    assert ref.shape[0] == count and np.abs(pcm - np.clip(ref, -1, 1)).max() <= 1.0 / 32767.0
+    assert np.abs(pcm).max() > 0.05                                      # (the window is not silence)
+    # the video samples still start where the video track says
+    va, vb = tk[0]
+    lo, hi = find_in(buf, va, vb, stbl + ("stco",))
+    v_off = struct.unpack(">III", buf[lo:lo + 12])[2]
+    assert buf[v_off:v_off + 2] == b"\xff\xd8"
