@@ -9,6 +9,13 @@ window, centred frames with zero padding, 31-bin median filters, power-2 soft ma
 bands).  **parity unpinned**: there is no librosa here to generate reference vectors, so tests check the
 mathematical properties (STFT/iSTFT round trip, mask partition of unity, mel filter known answers, monotone T).
 It is host-side, millisecond-scale work per clip and stays on the CPU.
+
+Two places where librosa's own behaviour changed between releases - the reference does not pin librosa
+(pyproject.toml), so both are explicit here instead of silently picked:
+* ``STFT_PAD_MODE``: centred frames are padded with zeros since librosa 0.10 ("constant"), by reflection before;
+* ``load`` resamples with ``soxr_hq`` since 0.10 (``kaiser_best`` before); neither library exists offline, this module
+  uses scipy's polyphase ``resample_poly`` - a third band-limited resampler.  The schedule is a cumulative sum of a
+  128-band envelope, so the choice moves T by far less than one frame (tests/test_audio.py bounds both effects).
 """
 from __future__ import annotations
 
@@ -17,6 +24,7 @@ import numpy as np
 N_FFT = 2048
 HOP = N_FFT // 4
 SR = 22050
+STFT_PAD_MODE = "constant"      # librosa >= 0.10; "reflect" reproduces librosa < 0.10
 
 
 def load_audio(path, sr: int = SR, mono: bool = True, offset: float = 0.0, duration=None):
@@ -45,9 +53,10 @@ def _hann(n: int) -> np.ndarray:
     return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)).astype(np.float32)      # periodic hann
 
 
-def stft(y: np.ndarray, n_fft: int = N_FFT, hop: int = HOP) -> np.ndarray:
-    """Centred STFT, zero padding, hann window -> complex64 [1 + n_fft/2, 1 + len(y)//hop]."""
-    ypad = np.pad(y.astype(np.float32), n_fft // 2, mode="constant")
+def stft(y: np.ndarray, n_fft: int = N_FFT, hop: int = HOP, pad_mode: str = None) -> np.ndarray:
+    """Centred STFT (frames padded per ``pad_mode`` / ``STFT_PAD_MODE``), hann window -> complex64
+    [1 + n_fft/2, 1 + len(y)//hop]."""
+    ypad = np.pad(y.astype(np.float32), n_fft // 2, mode=pad_mode or STFT_PAD_MODE)
     n_frames = 1 + (len(ypad) - n_fft) // hop
     idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
     frames = ypad[idx] * _hann(n_fft)[None, :]

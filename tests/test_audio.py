@@ -72,3 +72,27 @@ def test_get_timesteps_arr_properties():
     raw = get_timesteps_arr(str(WAV), offset=2, duration=2, fps=fps)
     assert np.allclose(half, 0.5 * raw + 0.5 * np.linspace(0, 1, 12))
     assert not np.allclose(raw, np.linspace(0, 1, 12), atol=0.02)      # audio really bends the schedule
+
+
+def test_librosa_version_choices_move_T_by_less_than_a_frame(monkeypatch):
+    """The reference does not pin librosa; its STFT padding changed ("reflect" < 0.10 <= "constant") and so did ``load``'s
+    resampler.  Both effects on the schedule are bounded here: at 30 fps a frame is 1/n of the [0, 1] range."""
+    fps, offset, duration = 30, 2, 2
+    n = duration * fps
+    base = get_timesteps_arr(str(WAV), offset=offset, duration=duration, fps=fps)
+    monkeypatch.setattr(audio, "STFT_PAD_MODE", "reflect")
+    refl = get_timesteps_arr(str(WAV), offset=offset, duration=duration, fps=fps)
+    monkeypatch.setattr(audio, "STFT_PAD_MODE", "constant")
+    assert np.abs(refl - base).max() < 0.5 / n
+    # the fixture is native 22.05 kHz (``load`` does not resample it), so a 2x round trip - polyphase up, FFT-based down -
+    # stands in for "a different band-limited resampler" in ``load``
+    from scipy.signal import resample
+    real_load = audio.load_audio
+
+    def fft_load(path, sr=audio.SR, mono=True, offset=0.0, duration=None):
+        y, native = real_load(path, sr=44100, mono=mono, offset=offset, duration=duration)
+        return resample(y, int(round(len(y) * sr / native))).astype(np.float32), sr
+
+    monkeypatch.setattr(audio, "load_audio", fft_load)
+    other = get_timesteps_arr(str(WAV), offset=offset, duration=duration, fps=fps)
+    assert np.abs(other - base).max() < 0.5 / n
