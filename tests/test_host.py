@@ -147,6 +147,28 @@ def test_scheduler_coefficients_equal_oracle_step():
         DDIMScheduler().set_timesteps(0)
 
 
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction"])
+def test_coefficient_table_reproduces_the_forward_marginals(ptype):
+    """The fused kernel applies x <- c_x x + c_e out per step with the PRODUCT scheduler's table: fed the true noise, the 50
+    steps of the BASELINE schedule must walk x_t = sqrt(a_t) x0 + sqrt(1 - a_t) eps down the marginals to t = 0 (DDIM with
+    eta = 0, Song et al. 2021 eq. 12) - a property of the published sampler, independent of the oracle restatement."""
+    from stable_diffusion_videos_amd.scheduler import DDIMScheduler
+    s = DDIMScheduler(prediction_type=ptype)
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == list(range(981, 0, -20))
+    tab = s.coefficient_table(0.0).double()
+    a = s.alphas_cumprod.double()
+    g = torch.Generator().manual_seed(5)
+    x0, eps = torch.randn(64, generator=g, dtype=torch.float64), torch.randn(64, generator=g, dtype=torch.float64)
+    x = a[981].sqrt() * x0 + (1 - a[981]).sqrt() * eps
+    for i, t in enumerate(s.timesteps.tolist()):
+        out = eps if ptype == "epsilon" else a[t].sqrt() * eps - (1 - a[t]).sqrt() * x0
+        x = tab[i, 0] * x + tab[i, 1] * out
+        a_p = a[t - 20] if t - 20 >= 0 else a[0]
+        assert torch.allclose(x, a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps, atol=2e-5), t      # (the table is fp32)
+    assert float(tab[:, 2].abs().max()) == 0.0                                                  # eta = 0: no noise term
+
+
 def test_partition_frames_covers_every_frame_once():
     from stable_diffusion_videos_amd.parallel import partition_frames
     for counts, skips in (([60], None), ([80, 80, 80], None), ([12, 6, 18], [3, 0, 17]), ([3, 3], None), ([1], None)):

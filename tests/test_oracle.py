@@ -76,6 +76,28 @@ def test_ddim_schedule_known_answers():
     assert torch.allclose(out, (a_p ** 0.5 * a_t ** 0.5 + (1 - a_p) ** 0.5 * (1 - a_t) ** 0.5) * x)
 
 
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction"])
+def test_ddim_chain_reproduces_the_forward_marginals(ptype):
+    """A check that does not lean on diffusers: DDIM with eta = 0 (Song et al. 2021, eq. 12) fed the TRUE noise maps
+    x_t = sqrt(a_t) x0 + sqrt(1 - a_t) eps onto x_s = sqrt(a_s) x0 + sqrt(1 - a_s) eps for the same (x0, eps) - chained
+    over all 50 steps of the BASELINE schedule it must land on the t = 0 marginal with final_alpha_cumprod = a[0]
+    (set_alpha_to_one=False).  For v-prediction the model output is v = sqrt(a_t) eps - sqrt(1 - a_t) x0."""
+    g = torch.Generator().manual_seed(3)
+    x0, eps = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64), torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    s = DDIMScheduler(prediction_type=ptype)
+    s.set_timesteps(50)
+    a = s.alphas_cumprod.double()
+    t0 = int(s.timesteps[0])
+    x = a[t0].sqrt() * x0 + (1 - a[t0]).sqrt() * eps
+    for t in s.timesteps.tolist():
+        out = eps if ptype == "epsilon" else a[t].sqrt() * eps - (1 - a[t]).sqrt() * x0
+        x = s.step(out, t, x)
+        prev = t - 20
+        a_p = a[prev] if prev >= 0 else a[0]
+        assert torch.allclose(x, a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps, atol=1e-6), t
+    assert torch.allclose(x, a[0].sqrt() * x0 + (1 - a[0]).sqrt() * eps, atol=1e-6)
+
+
 def test_tiny_oracle_end_to_end_runs():
     """The oracle's full control flow on a tiny architecture: shapes, range, determinism."""
     torch.manual_seed(0)
