@@ -320,7 +320,10 @@ def test_local_checkpoint_directory_round_trip(tmp_path):
            .replace(".to_out.0.", ".proj_attn."): v for k, v in v_sd.items()}
     old["encoder.conv_in.weight"] = torch.zeros(1)          # extra (encoder) keys are ignored
     save_file(old, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    _write_clip_tokenizer(tmp_path / "tokenizer")
     pipe = StableDiffusionWalkPipeline.from_pretrained(str(tmp_path))
+    from transformers import CLIPTokenizer
+    assert isinstance(pipe.tokenizer, CLIPTokenizer) and not pipe.synthetic
     assert pipe.unet.config.block_out_channels == tuple(ucfg.block_out_channels)
     assert pipe.unet.config.attention_head_dim == tuple(ucfg.attention_head_dim)
     for k, v in u_sd.items():
@@ -329,6 +332,50 @@ def test_local_checkpoint_directory_round_trip(tmp_path):
         assert torch.equal(pipe.vae.state_dict[k], v), k
     with pytest.raises(FileNotFoundError):
         weights.load_component(tmp_path, "text_encoder", {})
+
+
+def _write_clip_tokenizer(d):
+    """A real (tiny) CLIP byte-level BPE vocabulary: the 256-symbol alphabet, its word-final variants, four merges that build
+    "cat</w>" and "dog</w>", and the two special tokens - enough for transformers.CLIPTokenizer to load and tokenise."""
+    import json
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    chars = [chr(c) for c in cs]
+    merges = [("c", "a"), ("ca", "t</w>"), ("d", "o"), ("do", "g</w>")]
+    vocab = chars + [c + "</w>" for c in chars] + [a + b for a, b in merges] + ["<|startoftext|>", "<|endoftext|>"]
+    d.mkdir(parents=True)
+    (d / "vocab.json").write_text(json.dumps({t: i for i, t in enumerate(vocab)}))
+    (d / "merges.txt").write_text("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    (d / "tokenizer_config.json").write_text(json.dumps(dict(
+        model_max_length=77, tokenizer_class="CLIPTokenizer", bos_token="<|startoftext|>", eos_token="<|endoftext|>",
+        unk_token="<|endoftext|>", pad_token="<|endoftext|>")))
+    return {t: i for i, t in enumerate(vocab)}
+
+
+def test_real_clip_tokenizer_is_used_when_the_checkpoint_has_one(tmp_path):
+    """embed_text (stable_diffusion_pipeline.py:809-820) tokenises with the checkpoint's CLIPTokenizer: a model directory
+    with tokenizer/vocab.json must load transformers' real class (the hash tokenizer is only the no-vocabulary stand-in),
+    and the call shape the pipeline uses - pad to 77 with EOS, truncate, BOS first - must come out of it."""
+    from transformers import CLIPTokenizer
+    from stable_diffusion_videos_amd import config
+    from stable_diffusion_videos_amd.text import HashTokenizer, load_tokenizer
+    v = _write_clip_tokenizer(tmp_path / "tokenizer")
+    tok = load_tokenizer(tmp_path, config.tiny_text())
+    assert isinstance(tok, CLIPTokenizer) and tok.model_max_length == 77
+    out = tok(["a cat", "a dog " + "cat " * 200], padding="max_length", max_length=tok.model_max_length, truncation=True,
+              return_tensors="pt")
+    ids = out.input_ids
+    bos, eos = v["<|startoftext|>"], v["<|endoftext|>"]
+    assert ids.shape == (2, 77) and ids.dtype == torch.int64
+    assert ids[0, :4].tolist() == [bos, v["a</w>"], v["cat</w>"], eos] and (ids[0, 4:] == eos).all()
+    assert ids[1, 0] == bos and ids[1, 1:3].tolist() == [v["a</w>"], v["dog</w>"]] and ids[1, -1] == eos
+    assert (ids[1, 3:-1] == v["cat</w>"]).all()                                   # truncated to 77, EOS kept last
+    assert isinstance(load_tokenizer(tmp_path / "nothing-here", config.tiny_text()), HashTokenizer)
 
 
 def test_realesrgan_surface_and_weights(tmp_path):
