@@ -438,6 +438,54 @@ def test_hot_kernels_do_not_spill():
         assert worst[0] <= limit, f"{name}: kernel {worst[1]} uses {worst[0]} B of scratch per lane (limit {limit})"
 
 
+def test_buffer_stores_are_followed_by_idle_slots_before_their_registers_change():
+    """ISA lint for the store hazard found in round 2: on gfx950 a `buffer_store_dwordx4` with an SGPR offset
+    does not sample all of its data at issue - a VALU write to the first data register in the next slot reached memory in
+    lanes 12..15 of every 16 - and the compiler's hazard table has no wait state for that form.  The epilogue therefore puts
+    `s_nop 7` behind every store and keeps data + address registers live across it.  This compiles the 256 x 320 tile to ISA
+    and checks exactly that: between a store and its s_nop nothing writes the store's data or address VGPRs."""
+    import re
+    import subprocess
+    import tempfile
+    from stable_diffusion_videos_amd import build as b
+    src = b.CSRC / "sdv_gemm.hip"
+    with tempfile.TemporaryDirectory() as tmp:
+        out = Path(tmp) / "gemm6.s"
+        cmd = [b.hipcc(), *b.FLAGS, *b.FAST_FLAGS, *b.EXTRA_FLAGS.get(src.name, []), "-DSDV_GEMM_ONLY_TILE6", "-S",
+               "--cuda-device-only", "-o", str(out), str(src)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln.split(";")[0].strip() for ln in out.read_text().splitlines()]
+    lines = [ln for ln in lines if ln and not ln.startswith(".") and not ln.endswith(":")]
+
+    def vregs(op):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", op)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", op)
+        return {int(m.group(1))} if m else set()
+
+    def written(ln):
+        mnem, _, rest = ln.partition(" ")
+        if not mnem.startswith(("v_", "ds_read", "buffer_load", "global_load", "scratch_load")) or mnem.startswith("v_cmp"):
+            return set()
+        return vregs(rest.split(",")[0].strip())
+
+    stores = [i for i, ln in enumerate(lines) if ln.startswith("buffer_store_dwordx4")]
+    assert len(stores) >= 100, "expected the staged epilogues of the seven 256 x 320 kernels"
+    for i in stores:
+        ops = [o.strip() for o in lines[i].partition(" ")[2].split(",")]
+        guarded = vregs(ops[0]) | vregs(ops[1])
+        assert len(guarded) >= 5, lines[i]
+        for j in range(i + 1, min(i + 400, len(lines))):      # (the scheduler may park a pass's conversions in between)
+            if lines[j].startswith("s_nop 7"):
+                break
+            assert not lines[j].startswith(("buffer_store", "s_cbranch", "s_branch", "s_endpgm")), (lines[i], lines[j])
+            assert not (written(lines[j]) & guarded), f"{lines[j]!r} overwrites a register of {lines[i]!r} before its s_nop"
+        else:
+            raise AssertionError(f"no s_nop 7 behind {lines[i]!r}")
+
+
 def test_generate_images_layout_with_a_stub_pipeline(tmp_path):
     """generate_images (reference image_generation.py:108-215): batching, ``{seed}{ext}`` file names, prompt_config.json
     and the argument errors - exercised on CPU with a stub that has the pipeline's call shapes."""
