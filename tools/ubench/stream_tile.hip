@@ -64,7 +64,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void stream_kernel(Args p) {
             else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // (a RAW barrier: __syncthreads() waits for vmcnt(0) first, which would drain the ring on every slab - the
+            //  first run of this probe did exactly that and showed no effect of `depth`)
+            __builtin_amdgcn_s_barrier();
             // "compute": touch the slab once (one ds_read_b128 per lane) and burn `spin` clocks
             const uint4 v = *(const uint4*)(smem + (s % MAXD) * SLAB + tid * 16);
             acc += v.x ^ v.y ^ v.z ^ v.w;
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void stream_kernel(Args p) {
                 const long long t0 = __builtin_readcyclecounter();
                 while (__builtin_readcyclecounter() - t0 < p.spin) {}
             }
-            __syncthreads();                                   // everyone is done with slot s % MAXD
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // everyone is done with slot s % MAXD
             if (issued < nslab) issue(issued++);
         }
         if (p.stores) {
@@ -81,13 +84,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void stream_kernel(Args p) {
                 __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long long)t * BM * p.N), 0, 0x7ffffff0, 0x00020000);
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 val = {acc, (unsigned)t, (unsigned)lane, (unsigned)wave};
-            for (int seg = 0; seg < p.N / 64; ++seg)
+            for (int seg = 0; seg < p.N / 64; ++seg) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = (wave + NWV * i) * 8 + rg;
                     __builtin_amdgcn_raw_buffer_store_b128(val, rc, (row * p.N + seg * 64) * 2 + pc * 16, 0, 0);
                     asm volatile("s_nop 7" ::"v"(val) : "memory");     // (the store hazard, see sdv_gemm.hip)
                 }
+                asm volatile("s_waitcnt vmcnt(40)" ::: "memory");       // (the 6-bit counter: never more than 44 stores in flight)
+            }
         }
     }
     if (acc == 0x12345678u) atomicAdd(p.sink, 1ull);
