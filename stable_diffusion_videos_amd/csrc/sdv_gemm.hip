@@ -28,18 +28,6 @@
 
 namespace {
 
-#ifdef SDV_GEMM_TIMING   // tools only: per-phase s_memtime stamps of workgroup 0 / wave 0 (never defined in the product build)
-__device__ long long* g_tbuf = nullptr;
-#define SDV_STAMP(slot)                                                                        \
-    do {                                                                                       \
-        if (g_tbuf && blockIdx.x == SDV_GEMM_TIMING && threadIdx.x == 0 && tstamp < 4096) {    \
-            g_tbuf[tstamp++] = ((long long)(slot) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffLL); \
-        }                                                                                      \
-    } while (0)
-#else
-#define SDV_STAMP(slot) do {} while (0)
-#endif
-
 // waves per SIMD the register allocator must leave room for: the 32-wide-K tiles are meant to run two workgroups
 // per CU (16 waves -> 4 per SIMD -> <= 128 VGPRs)
 // NST = K-tile buffers in LDS.  2: double buffer, one `vmcnt(0)` + barrier per tile (the small / 64-wide-K tiles).
@@ -73,10 +61,6 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     static_assert(FEAT != 8 || (BK == 64 && NST == 2), "fp8 tiles: 64 elements (64 bytes) per K tile, double buffered");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef SDV_GEMM_TIMING
-    int tstamp = 0;
-#endif
-    SDV_STAMP(0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -639,9 +623,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st;
                 }
             }
-            SDV_STAMP(5);
             __syncthreads();   // the vectors are staged AND every wave has left the K loop (the slabs alias a K-slab buffer)
-            SDV_STAMP(3);
             // LayerNorm folded into this GEMM (sdv_hip.h "ln_side"): the weights were pre-multiplied by gamma, so
             //   LN(x) W^T = rstd * (x (gamma o W)^T - mean * s) + (W beta + b),  s = row sums of gamma o W
             // side 1: (mean, rstd) belong to the output ROW (this lane's m), s to the output column;
@@ -1071,11 +1053,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             for (int b = 0; b < TM; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-        SDV_STAMP(1);
         kloop();
-        SDV_STAMP(2);
         epilogue();
-        SDV_STAMP(4);
         if (!has_next) break;
         vb += (int)gridDim.x;
         slot0 = (slot0 + nkt) & 1;
@@ -1159,13 +1138,6 @@ extern "C" int sdv_gemm_stats_slots(const sdv_gemm_args* args) { return sdv_gemm
 
 // 1 (default): the 8-wave tiles run as persistent workgroups (one per CU, walking tiles); 0: one workgroup per tile.  Returns
 // the previous setting.  Results are identical either way; this exists so tools/ can time both on the same box.
-#ifdef SDV_GEMM_TIMING
-extern "C" int sdv_gemm_debug_timing(void* buf) {
-    long long* b = (long long*)buf;
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf), &b, sizeof(b));
-}
-#endif
-
 extern "C" int sdv_gemm_set_persistent(int on) {
     const int prev = g_persistent;
     g_persistent = on ? 1 : 0;

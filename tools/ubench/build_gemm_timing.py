@@ -1,26 +1,73 @@
 #!/usr/bin/env python
-"""Tools-only build of the igemm with per-phase cycle stamps (-DSDV_GEMM_TIMING=<workgroup>, 256 x 320 tile only):
-workgroup <n>'s wave 0 writes s_memtime at kernel start (0), after tile setup (1), after the K loop (2), before / after the
-epilogue barrier (5 / 3) and after the epilogue (4) for every tile it walks.  Builds tools/ubench/libsdv_gemm_timing.so with
-the same C ABI + sdv_gemm_debug_timing(buf);  run   SDV_HIP_LIB=tools/ubench/libsdv_gemm_timing.so python tools/gemm_phases.py"""
+"""Tools-only build of the igemm with per-phase cycle stamps (256 x 320 tile only), made from a patched COPY of
+csrc/sdv_gemm.hip - the product source carries none of this: workgroup <n>'s wave 0 writes the shader clock at kernel start
+(0), after tile setup (1), after the K loop (2), before / after the epilogue barrier (5 / 3) and after the epilogue (4) for every
+tile it walks.  Builds tools/ubench/libsdv_gemm_timing.so with the same C ABI + sdv_gemm_debug_timing(buf); run
+    SDV_HIP_LIB=tools/ubench/libsdv_gemm_timing.so python tools/gemm_phases.py
+`build_gemm_timing.py notiming -DFOO=1` builds an unstamped variant with extra flags (libsdv_gemm_dbg<digits>.so)."""
 import subprocess
 import sys
+import tempfile
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from stable_diffusion_videos_amd import build as b  # noqa: E402
 
-b.build()
-src = b.CSRC / "sdv_gemm.hip"
-wg = sys.argv[1] if len(sys.argv) > 1 else "0"
-extra = sys.argv[2:]          # extra -D flags
-name = "libsdv_gemm_timing.so" if wg != "notiming" else "libsdv_gemm_dbg%s.so" % "".join(c for c in "".join(extra) if c.isdigit())
-others = [b.OBJDIR / f"{s.stem}.o" for s in b.sources() if s.name != src.name]
-obj = Path(__file__).resolve().parent / "gemm_timing.o"
-subprocess.run([b.hipcc(), *b.FLAGS, *b.FAST_FLAGS, *b.EXTRA_FLAGS[src.name], *([f"-DSDV_GEMM_TIMING={wg}"] if wg != "notiming" else []), *extra, "-DSDV_GEMM_ONLY_TILE6", "-c",
-                str(src), "-o", str(obj)], check=True)
-out = Path(__file__).resolve().parent / name
-subprocess.run([b.hipcc(), "--offload-arch=" + b.ARCH, "-shared", "-fPIC", str(obj), *map(str, others), "-o", str(out)], check=True)
-obj.unlink()
-print("built", out)
+MACRO = """
+__device__ long long* g_tbuf = nullptr;
+#define SDV_STAMP(slot)                                                                        \\
+    do {                                                                                       \\
+        if (g_tbuf && blockIdx.x == SDV_GEMM_TIMING && threadIdx.x == 0 && tstamp < 4096) {    \\
+            g_tbuf[tstamp++] = ((long long)(slot) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffLL); \\
+        }                                                                                      \\
+    } while (0)
+"""
+ENTRY = """extern "C" int sdv_gemm_debug_timing(void* buf) {
+    long long* b = (long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf), &b, sizeof(b));
+}
+
+"""
+# (anchor in the product source, replacement) - every anchor must occur exactly once
+PATCHES = [
+    ("namespace {\n", "namespace {\n" + MACRO),
+    ("    extern __shared__ __attribute__((aligned(16))) char smem[];\n",
+     "    extern __shared__ __attribute__((aligned(16))) char smem[];\n    int tstamp = 0;\n    SDV_STAMP(0);\n"),
+    ("            __syncthreads();   // the vectors are staged AND every wave has left the K loop",
+     "            SDV_STAMP(5);\n            __syncthreads();   SDV_STAMP(3);   // the vectors are staged AND every wave has left the K loop"),
+    ("        kloop();\n", "        SDV_STAMP(1);\n        kloop();\n        SDV_STAMP(2);\n"),
+    ("        epilogue();\n", "        epilogue();\n        SDV_STAMP(4);\n"),
+    ('extern "C" int sdv_gemm_set_persistent(int on) {', ENTRY + 'extern "C" int sdv_gemm_set_persistent(int on) {'),
+]
+
+
+def stamped_source(text: str) -> str:
+    for old, new in PATCHES:
+        assert text.count(old) == 1, f"build_gemm_timing: anchor {old[:50]!r} occurs {text.count(old)} times - update the patch"
+        text = text.replace(old, new)
+    return text
+
+
+def main():
+    b.build()
+    src = b.CSRC / "sdv_gemm.hip"
+    wg = sys.argv[1] if len(sys.argv) > 1 else "0"
+    extra = sys.argv[2:]          # extra -D flags
+    here = Path(__file__).resolve().parent
+    name = "libsdv_gemm_timing.so" if wg != "notiming" else "libsdv_gemm_dbg%s.so" % "".join(c for c in "".join(extra) if c.isdigit())
+    others = [b.OBJDIR / f"{s.stem}.o" for s in b.sources() if s.name != src.name]
+    with tempfile.TemporaryDirectory() as tmp:
+        patched = Path(tmp) / "sdv_gemm_timing.hip"
+        patched.write_text(stamped_source(src.read_text()) if wg != "notiming" else src.read_text())
+        obj = Path(tmp) / "gemm_timing.o"
+        subprocess.run([b.hipcc(), *b.FLAGS, *b.FAST_FLAGS, *b.EXTRA_FLAGS[src.name], "-I", str(b.CSRC),
+                        *([f"-DSDV_GEMM_TIMING={wg}"] if wg != "notiming" else []), *extra, "-DSDV_GEMM_ONLY_TILE6", "-c", str(patched),
+                        "-o", str(obj)], check=True)
+        out = here / name
+        subprocess.run([b.hipcc(), "--offload-arch=" + b.ARCH, "-shared", "-fPIC", str(obj), *map(str, others), "-o", str(out)], check=True)
+    print("built", out)
+
+
+if __name__ == "__main__":
+    main()
