@@ -529,3 +529,21 @@ def test_generate_images_layout_with_a_stub_pipeline(tmp_path):
         generate_images(pipe, "a cat", push_to_hub=True, repo_id="x/y", output_dir=tmp_path, name="hub2")
     with pytest.raises(FileExistsError):
         generate_images(pipe, "a cat", seeds=[1], output_dir=tmp_path, name="run")
+
+
+def test_bench_reads_the_committed_pmc_profile():
+    """bench.py folds the committed rocprofv3 --pmc summary of its default batch size into the JSON line (`roofline.traffic`,
+    `attention.mfma_busy_pmc`): the file must parse and carry the two kernels the bench looks up."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pmc = bench.pmc_profile(128)
+    tr = bench.dominant_kernel_traffic(pmc)
+    assert tr and tr["kernel"].startswith("igemm_kernel<4, 2, 2, 5, 64, true")
+    assert 1e9 < tr["fetch_bytes"] < 2e10 and 1e8 < tr["write_bytes"] < 5e9
+    shapes = [dict(kind="attention", dh=40, Lq=4096, Lk=4096, B=256, H=8, tflops=800.0)]
+    att = bench.attention_object(shapes, pmc)
+    assert att["shape"]["dh"] == 40 and 0.3 < att["mfma_busy_pmc"] < 0.9 and att["issued_tflops"] == 1120.0
+    assert bench.pmc_profile(7) == {}                      # no profile for that batch size: the fields stay null
+
