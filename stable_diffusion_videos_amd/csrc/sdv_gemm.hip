@@ -489,18 +489,26 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         body(std::false_type{}, std::false_type{}, 0);
     } else {
     // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
+    // The barriers here are RAW (own LDS reads retired + s_barrier): __syncthreads() is lowered to s_waitcnt vmcnt(0) +
+    // s_barrier, and in a persistent workgroup that would make the first slab of every tile wait for the PREVIOUS tile's
+    // stores - every load this loop depends on has its own explicit wait below.
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     stage(slot0, !landed);
     // (a prefetched first slab was waited for before the previous tile's epilogue barrier; waiting again here would
     //  also wait for that epilogue's STORES, which may drain behind this tile's first MFMAs instead)
     if (!(PERSIST && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int kt = 0; kt + 1 < nkt; ++kt) {
-        __syncthreads();
+        lds_barrier();
         stage((slot0 + kt + 1) & 1);
         compute((slot0 + kt) & 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // last K slab (kept out of the loop: the re-pointing below must not add register pressure to the steady state)
-    __syncthreads();
+    lds_barrier();
     if (PERSIST && has_next) {
         // every wave is past the MFMAs of slab nkt-2, so its slot is free - point the addressing at the next tile and
         // start its first slab
