@@ -880,7 +880,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 // s_waitcnt lgkmcnt(0): a wave's DS ops execute in order, the fence only keeps the COMPILER from moving the slab
                 // accesses (differently typed views of the same bytes) across each other; with two slabs per wave it sits where
                 // the older ops have long completed.
-                auto lds_fence = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+                // (experiment: compiler-only fence - a wave's DS ops execute in order, no hardware wait is needed)
+                auto lds_fence = [&]() { asm volatile("" ::: "memory"); };
                 park(0);
                 lds_fence();
                 fetch(0);
