@@ -631,7 +631,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st;
                 }
             }
-            __syncthreads();   // the vectors are staged AND every wave has left the K loop (the slabs alias a K-slab buffer)
+            // (the epilogue barrier - the vectors are staged AND every wave has left the K loop, whose buffers the slabs alias -
+            //  sits inside run(), behind the first residual loads: their latency overlaps the barrier wait)
             // LayerNorm folded into this GEMM (sdv_hip.h "ln_side"): the weights were pre-multiplied by gamma, so
             //   LN(x) W^T = rstd * (x (gamma o W)^T - mean * s) + (W beta + b),  s = row sums of gamma o W
             // side 1: (mean, rstd) belong to the output ROW (this lane's m), s to the output column;
@@ -870,18 +871,25 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     }
                 };
 
-                if constexpr (FEAT == 3) rowacc[lane_e] = 0.f;
                 if constexpr (F32) {
                     if (has_r) {
 #pragma unroll
                         for (int pi = 0; pi < DEPTH && pi < NP; ++pi) load_res(pi);
                     }
                 }
+                // exactly one run() executes per tile, and every wave takes the same one.  RAW barrier (own LDS ops retired +
+                // s_barrier): __syncthreads() would add s_waitcnt vmcnt(0) and wait for the residual rows issued just above;
+                // the loads this barrier publishes (the last K slab, the next tile's first slab) were waited for explicitly.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (FEAT == 3) rowacc[lane_e] = 0.f;
                 // Slab hand-overs (write -> read of the same slab, read -> re-write with a single slab) are fenced with
                 // s_waitcnt lgkmcnt(0): a wave's DS ops execute in order, the fence only keeps the COMPILER from moving the slab
                 // accesses (differently typed views of the same bytes) across each other; with two slabs per wave it sits where
                 // the older ops have long completed.
-                auto lds_fence = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+                // (experiment: compiler-only fence - a wave's DS ops execute in order, no hardware wait is needed)
+                auto lds_fence = [&]() { asm volatile("" ::: "memory"); };
                 park(0);
                 lds_fence();
                 fetch(0);
