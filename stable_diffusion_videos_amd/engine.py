@@ -29,6 +29,17 @@ from .weights import StateDict, conv_w, conv_w_c4, geglu_interleave, lin_w, ln_f
 BF16 = torch.bfloat16
 F32 = torch.float32
 
+# Optional block observer used by the block-wise parity tests (tests/test_blockwise_gpu.py): called as
+# TAP(diffusers_module_name, dict(kind=..., x=..., [x2=...], out=..., nimg=, H=, W=)) after every block of a forward /
+# decode with the block's actual HBM inputs and output, so that the oracle's module of the same name can be run on exactly
+# what the engine's block saw ("teacher forcing").  None = no overhead; never set inside a graph capture.
+TAP = None
+
+
+def _tap(name: str, kind: str, **kw):
+    if TAP is not None:
+        TAP(name, dict(kind=kind, **kw))
+
 
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
@@ -48,6 +59,7 @@ class _Res:
     """ResnetBlock2D: GN+SiLU -> conv3x3 (+temb bias) -> GN+SiLU -> conv3x3 (+ shortcut/residual)."""
 
     def __init__(self, sd: StateDict, p: str, device, groups: int, eps: float, has_temb: bool, fp8: bool = False):
+        self.name = p
         self.g1, self.b1 = vec(sd[p + ".norm1.weight"], device), vec(sd[p + ".norm1.bias"], device)
         self.w1 = conv_w(sd[p + ".conv1.weight"], device)
         self.c1_bias = vec(sd[p + ".conv1.bias"], device)
@@ -99,8 +111,11 @@ class _Res:
                            alpha=self.sx2 * self.sw2)
 
     def __call__(self, x, x2, nimg, H, W, step_ptr, circular):
-        if self.fp8:
-            return self._call_fp8(x, x2, nimg, H, W, step_ptr, circular)
+        out = self._call_fp8(x, x2, nimg, H, W, step_ptr, circular) if self.fp8 else self._call_bf16(x, x2, nimg, H, W, step_ptr, circular)
+        _tap(self.name, "resnet", x=x, x2=x2, out=out, nimg=nimg, H=H, W=W)
+        return out
+
+    def _call_bf16(self, x, x2, nimg, H, W, step_ptr, circular):
         HW = H * W
         h = hip.groupnorm(x, self.g1, self.b1, nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True, x2=x2)
         if self.wt is not None:
@@ -121,6 +136,7 @@ class _Transformer:
     """Transformer2DModel with one BasicTransformerBlock (self-attn, text cross-attn, GEGLU FF)."""
 
     def __init__(self, sd: StateDict, p: str, device, heads: int, groups: int):
+        self.name = p
         self.gn_g, self.gn_b = vec(sd[p + ".norm.weight"], device), vec(sd[p + ".norm.bias"], device)
         self.w_in, self.b_in = lin_w(sd[p + ".proj_in.weight"], device), vec(sd[p + ".proj_in.bias"], device)
         self.w_out, self.b_out = lin_w(sd[p + ".proj_out.weight"], device), vec(sd[p + ".proj_out.bias"], device)
@@ -179,6 +195,11 @@ class _Transformer:
                  sC=C * ldv)
 
     def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False):
+        out = self._forward(x, nimg, H, W, vt_ws, shared_prefix)
+        _tap(self.name, "transformer", x=x, out=out, nimg=nimg, H=H, W=W, shared_prefix=shared_prefix)
+        return out
+
+    def _forward(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False):
         """x: [nimg*HW, C] tokens.  With ``shared_prefix`` x holds only nimg/2 samples whose two CFG copies
         (unconditional / conditional) are still identical: everything up to the cross-attention - GroupNorm, proj_in,
         the whole self-attention, the cross-attention query - is computed ONCE, and the batch doubles where the
@@ -395,6 +416,7 @@ class UNetEngine:
         nb = nimg // 2 if shared else nimg
         conv_in = hip.conv3x3_c4 if self.conv_in_c4 else hip.conv3x3_cin_small
         h = conv_in(x[: nb * H * W], self.conv_in_w, self.conv_in_b, nimg=nb, H=H, W=W, circular=circ)
+        _tap("conv_in", "conv", x=x[: nb * H * W], out=h, nimg=nb, H=H, W=W)
         if shared:
             h0 = torch.empty((nimg * H * W, h.shape[1]), dtype=BF16, device=self.device)   # skip tensor for the up path
             h0[: nb * H * W].copy_(h)
@@ -413,14 +435,16 @@ class UNetEngine:
                 skips.append(h)
             if blk["down"] is not None:
                 wd, bd = blk["down"]
+                h_in = h
                 h = hip.conv3x3(h, wd, bd, nimg=nimg, H=hh, W=ww, mode=2, circular=circ)
+                _tap(f"down_blocks.{bi}.downsamplers.0", "down", x=h_in, out=h, nimg=nimg, H=hh, W=ww)
                 hh, ww = (hh + 1) // 2, (ww + 1) // 2
                 skips.append(h)
         r0, t0, r1 = self.mid
         h = r0(h, None, nimg, hh, ww, step_ptr, circ)
         h = t0(h, nimg, hh, ww, self._vt(nimg, t0.C, hh * ww))
         h = r1(h, None, nimg, hh, ww, step_ptr, circ)
-        for blk in self.up:
+        for bi, blk in enumerate(self.up):
             for j, r in enumerate(blk["res"]):
                 h = r(h, skips.pop(), nimg, hh, ww, step_ptr, circ)
                 if blk["attn"]:
@@ -428,13 +452,17 @@ class UNetEngine:
                     h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww))
             if blk["up"] is not None:
                 wu, bu = blk["up"]
+                h_in = h
                 h = hip.upconv3x3_phase(h, wu, bu, nimg=nimg, H=hh, W=ww, circular=circ)      # Upsample2D: nearest 2x + conv
+                _tap(f"up_blocks.{bi}.upsamplers.0", "up", x=h_in, out=h, nimg=nimg, H=hh, W=ww)
                 hh, ww = 2 * hh, 2 * ww
+        h_in = h
         h = hip.groupnorm(h, self.out_g, self.out_b, nimg=nimg, HW=hh * ww, groups=self.groups, eps=self.eps, silu=True)
         eps = torch.empty((nimg, hh, ww, self.cfg.out_channels), dtype=F32, device=self.device)
         # conv_out 320 -> 4 on the matrix cores (one 32-column MFMA tile, fp32 straight from the accumulators)
         hip.conv3x3(h, self.conv_out_w, self.conv_out_b, nimg=nimg, H=hh, W=ww, circular=circ, out_mode=1,
                     out_f32=eps.view(-1, self.cfg.out_channels))
+        _tap("conv_out", "out", x=h_in, out=eps.view(-1, self.cfg.out_channels), nimg=nimg, H=hh, W=ww)
         return eps
 
 
@@ -477,6 +505,11 @@ class VAEDecoderEngine:
         self.scale_factor = 2 ** (len(cfg.block_out_channels) - 1)
 
     def _attention(self, x, nimg, H, W):
+        out = self._attention_impl(x, nimg, H, W)
+        _tap("decoder.mid_block.attentions.0", "vae_attention", x=x, out=out, nimg=nimg, H=H, W=W)
+        return out
+
+    def _attention_impl(self, x, nimg, H, W):
         C, HW = x.shape[1], H * W
         n = hip.groupnorm(x, self.a_g, self.a_b, nimg=nimg, HW=HW, groups=self.groups, eps=1e-6, silu=False)
         qk = hip.linear(n, self.a_wqk, self.a_bqk)                                   # [M, 2C]
@@ -498,18 +531,23 @@ class VAEDecoderEngine:
         circ = self.tiled
         z = torch.empty((B * h * w, lc), dtype=BF16, device=self.device)
         hip.latent_affine(latents.contiguous(), self.pq_w, self.pq_b, 1.0 / self.cfg.scaling_factor, z, B * h * w, lc)
+        _tap("post_quant_conv", "post_quant", x=latents.reshape(B * h * w, lc), out=z, nimg=B, H=h, W=w)
         conv_in = hip.conv3x3_c4 if self.conv_in_c4 else hip.conv3x3_cin_small
         x = conv_in(z, self.conv_in_w, self.conv_in_b, nimg=B, H=h, W=w, circular=circ)
+        _tap("decoder.conv_in", "conv", x=z, out=x, nimg=B, H=h, W=w)
         x = self.mid_res[0](x, None, B, h, w, None, circ)
         x = self._attention(x, B, h, w)
         x = self.mid_res[1](x, None, B, h, w, None, circ)
-        for blk in self.up:
+        for bi, blk in enumerate(self.up):
             for r in blk["res"]:
                 x = r(x, None, B, h, w, None, circ)
             if blk["up"] is not None:
                 wu, bu = blk["up"]
+                x_in = x
                 x = hip.upconv3x3_phase(x, wu, bu, nimg=B, H=h, W=w, circular=circ)
+                _tap(f"decoder.up_blocks.{bi}.upsamplers.0", "up", x=x_in, out=x, nimg=B, H=h, W=w)
                 h, w = 2 * h, 2 * w
+        x_in = x
         x = hip.groupnorm(x, self.out_g, self.out_b, nimg=B, HW=h * w, groups=self.groups, eps=1e-6, silu=True)
         oc = self.cfg.out_channels
         u8 = torch.empty((B, h, w, oc), dtype=torch.uint8, device=self.device)
@@ -517,4 +555,5 @@ class VAEDecoderEngine:
         # conv_out 128 -> 3 on the matrix cores with the image epilogue (clamp(v / 2 + 0.5) -> round-half-even uint8)
         hip.conv3x3(x, self.conv_out_w, self.conv_out_b, nimg=B, H=h, W=w, circular=circ, out_mode=2,
                     out_f32=f32.view(-1, oc) if f32 is not None else None, out_u8=u8.view(-1, oc))
+        _tap("decoder.conv_out", "vae_out", x=x_in, out=f32.view(-1, oc) if f32 is not None else u8.view(-1, oc), nimg=B, H=h, W=w)
         return u8, f32
