@@ -1080,15 +1080,21 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 
 int g_persistent = 1;   // sdv_gemm_set_persistent(): A/B switch for tools/ (0 = one workgroup per tile, as in round 1)
 
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 ? dev : 0;
+}
+
+// CU count of the CURRENT device (per device: a process may drive several GPUs - SDV_FORCE_DEVICE tests, in-process fan-out)
 int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+    static int n[64] = {0};
+    const int dev = current_device();
+    if (!n[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+        int c = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+        n[dev] = c > 0 ? c : 256;
     }
-    return n;
+    return n[dev];
 }
 
 template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT = 0>
@@ -1100,11 +1106,12 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int SLOT = PERSIST && SLABS > TILE_BYTES ? SLABS : TILE_BYTES;
     constexpr int LDS = NST * SLOT + 3 * BN * 4 + WM * WN * 256;       // K-slab buffers + column vectors + row-stat accumulators
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    static bool attr_set = false;
-    if (LDS > 64 * 1024 && !attr_set) {
+    static unsigned long long attr_set = 0;   // one bit per device: the attribute belongs to the device's copy of the function
+    const unsigned long long dev_bit = 1ull << current_device();
+    if (LDS > 64 * 1024 && !(attr_set & dev_bit)) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS);
-        attr_set = true;
+        attr_set |= dev_bit;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const long long total = (long long)tiles_m * tiles_n * (a.batch > 0 ? a.batch : 1);

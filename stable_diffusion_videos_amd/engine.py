@@ -48,8 +48,17 @@ def _round_up(x: int, m: int) -> int:
 def _quant_w(w_bf16: torch.Tensor):
     """bf16 weight matrix -> (e4m3 bytes, per-tensor scale): w ~ q * scale, scale = amax / 448."""
     wf = w_bf16.float()
-    scale = float(wf.abs().max()) / hip.FP8_MAX
+    scale = max(float(wf.abs().max()), 1e-12) / hip.FP8_MAX       # (an all-zero matrix must not give scale 0 -> NaN weights)
+    assert scale > 0 and scale < float("inf"), "fp8 weight scale must be finite"
     return (wf / scale).to(hip.FP8).contiguous(), scale
+
+
+def _act_scale(y_bf16: torch.Tensor, prev) -> float:
+    """Per-tensor e4m3 scale of an activation from one calibration sample: 2 x amax / 448 (e4m3 is floating point, the factor
+    2 of head-room costs no precision), running maximum over the calibration forwards, floored so that an all-zero sample
+    (a zero-filled warm-up buffer) cannot produce scale 0 (division by zero in the GroupNorm apply)."""
+    s = 2.0 * max(float(y_bf16.float().abs().max()), 1e-6) / hip.FP8_MAX
+    return s if prev is None else max(s, prev)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -88,6 +97,7 @@ class _Res:
             self.w2_8, self.sw2 = _quant_w(self.w2)
             self.sx1: Optional[float] = None
             self.sx2: Optional[float] = None
+            self.calibrating = False           # UNetEngine.fp8_calibration(): widen the scales on every forward (eager only)
 
     def prepare_timesteps(self, emb: torch.Tensor):
         self.bias_table = hip.linear_small(emb, self.wt, self.bt, add=self.c1_bias, silu_in=True)
@@ -95,16 +105,19 @@ class _Res:
     def _call_fp8(self, x, x2, nimg, H, W, step_ptr, circular):
         HW = H * W
         gn = dict(nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True)
-        if self.sx1 is None:       # calibration (first, eager forward - never inside a graph capture)
-            self.sx1 = 2.0 * float(hip.groupnorm(x, self.g1, self.b1, x2=x2, **gn).float().abs().max()) / hip.FP8_MAX
+        # Activation scales: set by an explicit calibration run (UNetEngine.fp8_calibration - the pipeline runs a fixed pilot
+        # denoise BEFORE the graph warm-up, so the scales never come from a zero-filled capture buffer and are the same on every
+        # rank / resume); a bare engine (tests, tools) calibrates lazily on its first eager forward.
+        if self.sx1 is None or self.calibrating:
+            self.sx1 = _act_scale(hip.groupnorm(x, self.g1, self.b1, x2=x2, **gn), self.sx1)
         h8 = hip.groupnorm(x, self.g1, self.b1, x2=x2, fp8_scale=self.sx1, **gn)
         if self.wt is not None:
             h = hip.conv3x3(h8, self.w1_8, self.bias_table, nimg=nimg, H=H, W=W, circular=circular, step_ptr=step_ptr,
                             bias_step_stride=self.cout, alpha=self.sx1 * self.sw1)
         else:
             h = hip.conv3x3(h8, self.w1_8, self.c1_bias, nimg=nimg, H=H, W=W, circular=circular, alpha=self.sx1 * self.sw1)
-        if self.sx2 is None:
-            self.sx2 = 2.0 * float(hip.groupnorm(h, self.g2, self.b2, **gn).float().abs().max()) / hip.FP8_MAX
+        if self.sx2 is None or self.calibrating:
+            self.sx2 = _act_scale(hip.groupnorm(h, self.g2, self.b2, **gn), self.sx2)
         h8 = hip.groupnorm(h, self.g2, self.b2, fp8_scale=self.sx2, **gn)
         sc = hip.linear(x, self.ws, self.bs, x2=x2) if self.ws is not None else x
         return hip.conv3x3(h8, self.w2_8, self.c2_bias, nimg=nimg, H=H, W=W, residual=sc, circular=circular,
@@ -196,7 +209,7 @@ class _Transformer:
 
     def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False):
         out = self._forward(x, nimg, H, W, vt_ws, shared_prefix)
-        _tap(self.name, "transformer", x=x, out=out, nimg=nimg, H=H, W=W, shared_prefix=shared_prefix)
+        _tap(self.name, "transformer", x=x, out=out, nimg=nimg // 2 if shared_prefix else nimg, H=H, W=W, shared_prefix=shared_prefix)
         return out
 
     def _forward(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False):
@@ -212,6 +225,8 @@ class _Transformer:
             return self._call_unfolded(x, nimg, H, W, vt_ws, shared_prefix)
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
         h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)            # + (mean, rstd) of every token for norm1
+        _tap(self.name, "tf_in", x=x, out=h, nimg=nb, H=H, W=W)
+        h_in = h
         # --- self attention: LN1 lives inside the Q/K and V^T projections ---
         qs = hip.q_prescale(dh)       # softmax scale * log2(e), applied by the Q projections before their single rounding
         qk = hip.linear(h, self.wqk1, self.tqk1, alpha=qs, alpha_cols=C, ln=(st1, self.sqk1))   # [Mb, 2C] = [Q * qs | K]
@@ -226,6 +241,8 @@ class _Transformer:
         hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
                       scale=scale, k_off=C, q_prescaled=True)
         h, st2 = hip.linear(o, self.wo1, self.bo1, residual=h, want_stats=True)
+        _tap(self.name, "tf_attn1", x=h_in, out=h, nimg=nb, H=H, W=W)
+        h_in = h
         # --- cross attention on the text context (LN2 inside the Q projection) ---
         q = hip.linear(h, self.wq2, self.tq2, alpha=qs, ln=(st2, self.sq2))
         o2 = torch.empty((M, C), dtype=BF16, device=x.device)
@@ -244,14 +261,19 @@ class _Transformer:
             st3 = hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
                            sX=Mb * C, sW=0, sC=Mb * C, sR=0, want_stats=True)
             h = h2
+        _tap(self.name, "tf_attn2", x=h_in, out=h, nimg=nb, H=H, W=W, shared_prefix=shared_prefix)
+        h_in = h
         # --- GEGLU feed-forward (LN3 inside ff.net.0) ---
         g = hip.linear(h, self.wff1, self.bff1, epi=1, ln=(st3, self.sff1))   # [M, 4C]
         h = hip.linear(g, self.wff2, self.bff2, residual=h)
+        _tap(self.name, "tf_ff", x=h_in, out=h, nimg=nimg, H=H, W=W)
         if not shared_prefix:
-            return hip.linear(h, self.w_out, self.b_out, residual=x)
-        out = torch.empty((M, C), dtype=BF16, device=x.device)           # residual x is the shared (nb-sample) input
-        hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
-                 sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+            out = hip.linear(h, self.w_out, self.b_out, residual=x)
+        else:
+            out = torch.empty((M, C), dtype=BF16, device=x.device)           # residual x is the shared (nb-sample) input
+            hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
+                     sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+        _tap(self.name, "tf_out", x=h, x2=x, out=out, nimg=nimg, H=H, W=W, shared_prefix=shared_prefix)
         return out
 
 
@@ -358,6 +380,25 @@ class UNetEngine:
         self.groups, self.eps = g, eps
         self._vt_ws: Dict[tuple, torch.Tensor] = {}
         self.num_steps = 0
+        self.fp8_calibrated = False
+
+    def fp8_calibration(self, on: bool):
+        """While on, every (eager) forward WIDENS the e4m3 activation scales of the ResBlock convs to cover what it sees
+        (running maximum); turning it off freezes them and marks the engine calibrated.  Host synchronising - never inside a
+        graph capture."""
+        for r in self.res:
+            if r.fp8:
+                r.calibrating = bool(on)
+        if not on:
+            self.fp8_calibrated = True
+
+    def fp8_scales(self):
+        return [(r.sx1, r.sx2) for r in self.res if r.fp8]
+
+    def set_fp8_scales(self, scales):
+        for r, (a, b) in zip([r for r in self.res if r.fp8], scales):
+            r.sx1, r.sx2 = float(a), float(b)
+        self.fp8_calibrated = True
 
     # -- per-walk preparation ----------------------------------------------------------------
     def prepare_timesteps(self, timesteps: Sequence[int]):
@@ -385,6 +426,16 @@ class UNetEngine:
         if key not in self._vt_ws:
             self._vt_ws[key] = torch.zeros((nimg, C, _round_up(HW, 64)), dtype=BF16, device=self.device)
         return self._vt_ws[key]
+
+    def release(self, nimg: int):
+        """Free the per-batch-size buffers (cross-attention K / V^T, V^T workspaces) of ``nimg`` samples.  Only when no
+        captured graph of that batch size is alive - they hold raw pointers into these buffers."""
+        for t in self.tfm:
+            for key in [k for k in t.ctx_by_len if k[0] == nimg]:
+                del t.ctx_by_len[key]
+            t.ctx.pop(nimg, None)
+        for key in [k for k in self._vt_ws if k[0] == nimg]:
+            del self._vt_ws[key]
 
     def reserve(self, nimg: int, H: int, W: int):
         """Allocate the persistent workspaces outside of graph capture."""

@@ -121,7 +121,7 @@ def lerp_batch(a: torch.Tensor, b: torch.Tensor, T: torch.Tensor) -> torch.Tenso
 
 @lerp_batch.register_fake
 def _(a, b, T):
-    return a.new_empty((T.numel(),) + tuple(a.shape[1:] if a.shape[0] == 1 else a.shape))
+    return a.new_empty((T.numel(),) + tuple(a.shape[1:] if a.shape[0] == 1 else a.shape), dtype=torch.float32)   # always fp32
 
 
 @_lib.custom_op("sdv::slerp_batch", mutates_args=())
@@ -135,7 +135,7 @@ def slerp_batch(v0: torch.Tensor, v1: torch.Tensor, T: torch.Tensor, dot_thresho
 
 @slerp_batch.register_fake
 def _(v0, v1, T, dot_threshold=0.9995):
-    return v0.new_empty((T.numel(),) + tuple(v0.shape[1:] if v0.shape[0] == 1 else v0.shape))
+    return v0.new_empty((T.numel(),) + tuple(v0.shape[1:] if v0.shape[0] == 1 else v0.shape), dtype=torch.float32)
 
 
 OPS = ("linear", "conv3x3", "upsample_conv3x3", "attention", "group_norm", "layer_norm", "cfg_ddim_step", "lerp_batch",

@@ -93,48 +93,35 @@ def broadcast_state_dict(sd: Dict[str, torch.Tensor], shapes: Dict[str, tuple], 
                          ) -> Dict[str, torch.Tensor]:
     """One-time weight distribution: rank ``src`` holds ``sd``; everyone returns an identical dict.
 
-    Matrices travel as ONE packed bf16 buffer and vectors (biases, norm scales) as ONE packed fp32 buffer:
-    two large broadcasts (~1.7 GB + a few MB for the UNet) instead of ~700 small ones, which is what a
-    point-to-point xGMI fabric wants.  bf16 is what the kernels consume, so nothing is lost."""
+    All parameters travel as ONE packed fp32 buffer (3.4 GB for the SD-1.4 UNet - a single large broadcast, which is what a
+    point-to-point xGMI fabric wants, instead of ~700 small ones).  fp32 MASTERS, not bf16: the engines fold LayerNorm gains
+    into weights, sum the up-convs' coincident taps and quantise to e4m3 from what they are given, and each of those must
+    round ONCE from the checkpoint's values - with a bf16 transport a real fp32 / fp16 checkpoint gave an N-rank run that
+    differed from the 1-rank run.  Every entry starts on a 16-byte boundary.  The matrices are returned as views
+    of the packed buffer (the engines convert / re-lay them out into their own bf16 storage, after which the caller drops the
+    dict and the buffer is freed); the small vectors are cloned so that nothing the engines keep pins the buffer."""
     rank, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
         return sd
     # (a 1-rank process group still takes the broadcast path: that is how the RCCL code is exercised on a 1-GPU box)
-    mats = [k for k, s in shapes.items() if len(s) > 1]
-    vecs = [k for k, s in shapes.items() if len(s) == 1]
-    n_m = sum(int(torch.tensor(shapes[k]).prod()) for k in mats)
-    n_v = sum(int(shapes[k][0]) for k in vecs)
     use_gpu = dist.get_backend() == "nccl"
     dev = torch.device(device) if use_gpu else torch.device("cpu")
-    buf_m = torch.empty(n_m, dtype=torch.bfloat16, device=dev)
-    buf_v = torch.empty(n_v, dtype=torch.float32, device=dev)
+    offs, o = {}, 0
+    for k, shp in shapes.items():
+        n = 1
+        for d in shp:
+            n *= int(d)
+        offs[k] = (o, n)
+        o += (n + 3) // 4 * 4                  # 4 floats = 16 bytes
+    buf = torch.empty(o, dtype=torch.float32, device=dev)
     if rank == src:
-        o = 0
-        for k in mats:
-            n = sd[k].numel()
-            buf_m[o:o + n] = sd[k].reshape(-1).to(dev, torch.bfloat16)
-            o += n
-        o = 0
-        for k in vecs:
-            n = sd[k].numel()
-            buf_v[o:o + n] = sd[k].reshape(-1).to(dev, torch.float32)
-            o += n
-    dist.broadcast(buf_m, src=src)
-    dist.broadcast(buf_v, src=src)
-    # RCCL: the buffers stay in HBM and the engines re-lay-out straight from these device views (bf16 matrices, fp32
-    # vectors) - no D2H copy, no fp32 widening on the host cores that all ranks of a node share.
+        for k, (a, n) in offs.items():
+            buf[a:a + n] = sd[k].reshape(-1).to(dev, torch.float32)
+    dist.broadcast(buf, src=src)
     out: Dict[str, torch.Tensor] = {}
-    o = 0
-    for k in mats:
-        n = int(torch.tensor(shapes[k]).prod())
-        v = buf_m[o:o + n].view(*shapes[k])
-        out[k] = v if use_gpu else v.float()
-        o += n
-    o = 0
-    for k in vecs:
-        n = int(shapes[k][0])
-        out[k] = buf_v[o:o + n] if use_gpu else buf_v[o:o + n].clone()
-        o += n
+    for k, (a, n) in offs.items():
+        v = buf[a:a + n].view(*shapes[k])
+        out[k] = v.clone() if len(shapes[k]) == 1 or n <= 4096 else v
     return out
 
 

@@ -5,7 +5,10 @@ Same public methods, keyword arguments, error behaviour, on-disk layout and ``pr
 the arithmetic behind them runs in hand-written gfx950 HIP kernels (libsdv_hip.so) instead of
 diffusers/ATen:
 
-    walk            :556-807   orchestration, resume, prompt_config.json (kept bit-for-bit, quirks included)
+    walk            :556-807   orchestration, prompt_config.json (same keys, same order); ``resume`` regenerates the
+                               MISSING-frame set - the reference's "continue after the last frame on disk" rule and its
+                               :747-752 quirk (a clip with exactly one missing frame is skipped) are deliberately NOT
+                               reproduced, see walk()
     make_clip_frames:481-554   T = linspace, batches, frame%06d.png
     generate_inputs :457-479   lerp(text embeddings) + slerp(noise) - ONE fused launch per batch, on device
     __call__        :191-455   CFG + 50-step DDIM loop (one hipGraph replay per step) + VAE decode + uint8
@@ -134,6 +137,14 @@ class StableDiffusionWalkPipeline:
                            "tokenizer (no checkpoint on disk) - outputs are for benchmarking / parity only", name, arch)
         if torch_dtype not in (None, torch.bfloat16, torch.float16, torch.float32, "fp8"):
             raise ValueError(f"unsupported torch_dtype {torch_dtype}")
+        if torch_dtype in (torch.float16, torch.float32):
+            # the reference passes torch_dtype through to diffusers (its own tests run float16, tests/test_pipeline.py:19-27);
+            # the HIP engines have ONE storage format - bf16 activations / weights, fp32 accumulation, fp32 latents - so the
+            # request cannot be honoured and must not be swallowed silently
+            import warnings
+            warnings.warn(f"from_pretrained(torch_dtype={torch_dtype}): the MI355X HIP engines store activations and weights as "
+                          "bfloat16 (fp32 accumulation, fp32 latents and scheduler state); this pipeline runs in bfloat16, not "
+                          f"{torch_dtype} - pipe.torch_dtype reports what actually runs", UserWarning, stacklevel=2)
         if model_dir is not None:
             ucfg = cfgs.unet_from_json(model_dir / "unet" / "config.json")
             vcfg = cfgs.vae_from_json(model_dir / "vae" / "config.json")
@@ -166,7 +177,8 @@ class StableDiffusionWalkPipeline:
         pipe.tiled = tiled
         pipe.fp8 = bool(fp8) or torch_dtype == "fp8"    # BASELINE config 5: e4m3 operands in the UNet's ResBlock convs
         pipe.synthetic = model_dir is None
-        pipe.torch_dtype = torch.bfloat16 if torch_dtype in (None, "fp8") else torch_dtype
+        pipe.torch_dtype = torch.bfloat16            # what the engines compute in (see the warning above)
+        pipe.requested_torch_dtype = torch_dtype
         if device is not None:
             pipe.to(device)
         return pipe
@@ -287,6 +299,32 @@ class StableDiffusionWalkPipeline:
             r.bias_table = t
         return key, coefs, len(ts)
 
+    def _calibrate_fp8(self, h: int, w: int, coefs, nsteps: int, guidance: float, cfg: bool):
+        """fp8 mode: fix the e4m3 activation scales of the UNet's ResBlock convs with ONE pilot denoise run, eager, before any
+        graph is warmed up or captured: one frame of seeded N(0,1) latents (seed 0, CPU generator) under the unconditional
+        context, all ``nsteps`` steps, scales = 2 x the running amax.  The pilot does not depend on the prompts, the batch, the
+        rank or where a resumed walk starts, so every rank and every re-run quantises identically (the scales used
+        to come from the graph warm-up's zero-filled buffers)."""
+        C = self.unet.cfg.in_channels
+        g = torch.Generator(device="cpu").manual_seed(0)
+        lat = torch.randn((1, h, w, C), generator=g, dtype=F32).to(self.device) * self.scheduler.init_noise_sigma
+        uncond = self._uncond_embeddings(None, 1)
+        nimg = 2 if cfg else 1
+        self.unet.prepare_context(torch.cat([uncond] * nimg))
+        self.unet.reserve(nimg, h, w)
+        x2 = torch.zeros((nimg * h * w, C), dtype=BF16, device=self.device)
+        step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        hip.latents_to_unet_input(lat, x2, cfg, lat.numel())
+        self.unet.fp8_calibration(True)
+        try:
+            for _ in range(nsteps):
+                eps = self.unet.forward(x2, nimg, h, w, step, cfg_shared=cfg and self.cfg_shared_prefix)
+                hip.cfg_ddim_step(eps, lat, x2, coefs, step, None, guidance, cfg, lat.numel())
+                hip.step_counter_add(step, 1)
+        finally:
+            self.unet.fp8_calibration(False)
+        torch.cuda.synchronize(self.device)
+
     def _graph_entry(self, key: tuple, nimg: int, B: int, h: int, w: int, cfg: bool, guidance: float, coefs, eta_noise):
         """Static buffers + a captured hipGraph of ONE denoise step (UNet forward + CFG/DDIM update + step++)."""
         if key in self._graphs:
@@ -297,6 +335,11 @@ class StableDiffusionWalkPipeline:
             ent = self._graphs.pop(old_key)
             ent["graph"] = None
             del ent
+            # the cross-attention K / V^T buffers and V^T workspaces are kept per batch size because captured graphs hold raw
+            # pointers into them: once no cached graph runs at that batch size any more they go too (a resumed walk with many
+            # short runs would otherwise leave one set per distinct batch size behind)
+            if not any(k[1] == old_key[1] for k in self._graphs) and old_key[1] != nimg:
+                self.unet.release(old_key[1])
         dev = self.device
         C = self.unet.cfg.in_channels
         ent = {
@@ -396,6 +439,8 @@ class StableDiffusionWalkPipeline:
         latents = latents.to(self.device, F32)
 
         sched_key, coefs, nsteps = self._schedule(num_inference_steps, eta)                       # :394
+        if getattr(self.unet, "fp8", False) and not self.unet.fp8_calibrated:
+            self._calibrate_fp8(h, w, coefs, nsteps, float(guidance_scale), do_cfg)
         # A ragged last batch (B frames where a graph for B' > B frames is already captured) is padded with copies of its
         # last frame and replays the big graph: a second capture would own a second multi-GB private pool for one call.
         # Only while the padding is at most a quarter of the big batch - 60 frames replayed as 128 would pay for 128.
@@ -498,9 +543,12 @@ class StableDiffusionWalkPipeline:
                          guidance_scale: float = 7.5, eta: float = 0.0, height: Optional[int] = None,
                          width: Optional[int] = None, upsample: bool = False, batch_size: int = 1,
                          image_file_ext: str = ".png", T: np.ndarray = None, skip: int = 0, negative_prompt: str = None,
-                         step: Optional[Tuple[int, int]] = None, stop: Optional[int] = None):
-        """Reference :481-554 (``stop`` is the extra upper frame bound used for frame sharding: frames [skip, stop) of the
-        clip are generated and written under their own indices)."""
+                         step: Optional[Tuple[int, int]] = None, stop: Optional[int] = None,
+                         frame_indices: Optional[List[int]] = None):
+        """Reference :481-554.  Two extensions for frame sharding / hole-filling resume: ``stop`` (frames [skip, stop) of the
+        clip are generated and written under their own indices) and ``frame_indices`` (an explicit, sorted list of the clip's
+        frames to generate - the missing frames of a resumed clip are then batched TOGETHER, ``batch_size`` at a time, instead
+        of one short batch per hole)."""
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         save_path = Path(save_path)
@@ -514,18 +562,22 @@ class StableDiffusionWalkPipeline:
                 self.upsampler = RealESRGANModel.from_pretrained("nateraw/real-esrgan")
             self.upsampler.to(self.device)
         stop = num_interpolation_steps if stop is None else stop
+        indices = list(range(skip, stop)) if frame_indices is None else [int(k) for k in frame_indices]
+        if any(k < 0 or k >= num_interpolation_steps for k in indices):
+            raise ValueError(f"frame_indices outside [0, {num_interpolation_steps})")
         batch_generator = self.generate_inputs(prompt_a, prompt_b, seed_a, seed_b,
-                                               (1, self.unet.in_channels, height // 8, width // 8), T[skip:stop],
+                                               (1, self.unet.in_channels, height // 8, width // 8), np.asarray(T)[indices],
                                                batch_size)
         num_batches = math.ceil(num_interpolation_steps / batch_size)
         log_prefix = "" if step is None else f"[{step[0]}/{step[1]}] "
         writer = self._writer or FrameWriter()
-        frame_index = skip
+        pos = 0
         for batch_idx, embeds_batch, noise_batch in batch_generator:
+            frame_index = indices[pos]
             if batch_size == 1:
                 msg = f"Generating frame {frame_index}"
             else:
-                msg = f"Generating frames {frame_index}-{frame_index + embeds_batch.shape[0] - 1}"
+                msg = f"Generating frames {frame_index}-{indices[pos + embeds_batch.shape[0] - 1]}"
             logger.info(f"{log_prefix}[{batch_idx}/{num_batches}] {msg}")
             outputs = self(latents=noise_batch, text_embeddings=embeds_batch, height=height, width=width,
                            guidance_scale=guidance_scale, eta=eta, num_inference_steps=num_inference_steps,
@@ -535,9 +587,9 @@ class StableDiffusionWalkPipeline:
                 # uint8 frames never leave HBM before the x4 network has run on the whole batch
                 outputs = numpy_to_pil(self.upsampler.upsample_u8(outputs).cpu().numpy())
             for image in outputs:
-                frame_filepath = save_path / (f"frame%06d{image_file_ext}" % frame_index)
+                frame_filepath = save_path / (f"frame%06d{image_file_ext}" % indices[pos])
                 writer.submit(image, frame_filepath)                                             # :553
-                frame_index += 1
+                pos += 1
         if self._writer is None:
             writer.close()
 
@@ -638,9 +690,13 @@ class StableDiffusionWalkPipeline:
         shares = parallel.partition_frame_list([c["todo"] for c in clips], world_size, rank)
 
         # pass 2: generate this rank's frames
+        # this rank's runs of consecutive frames, coalesced per clip: the holes of a resumed clip fill whole batches together
+        per_clip: Dict[int, List[int]] = {}
+        for ci, first, stop in shares:
+            per_clip.setdefault(ci, []).extend(range(first, stop))
         self._writer = FrameWriter()
         try:
-            for ci, first, stop in shares:
+            for ci, frames in per_clip.items():
                 c = clips[ci]
                 i, num_step = c["i"], c["num_step"]
                 audio_offset = audio_start_sec + sum(num_interpolation_steps[:i]) / fps          # :755
@@ -651,7 +707,7 @@ class StableDiffusionWalkPipeline:
                     eta=eta, height=height, width=width, upsample=upsample, batch_size=batch_size,
                     T=get_timesteps_arr(audio_filepath, offset=audio_offset, duration=audio_duration, fps=fps,
                                         margin=margin, smooth=smooth) if audio_filepath else None,
-                    skip=first, stop=stop, negative_prompt=negative_prompt, step=(i, len(prompts) - 1))
+                    frame_indices=frames, negative_prompt=negative_prompt, step=(i, len(prompts) - 1))
         finally:
             self._writer.close()
             self._writer = None

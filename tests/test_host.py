@@ -219,6 +219,24 @@ def test_no_silent_synthetic_fallback_and_scheduler_error(tmp_path):
         pipe._schedule(50, 0.0)
 
 
+def test_torch_dtype_is_reported_not_swallowed():
+    """The reference forwards torch_dtype to diffusers (its tests run float16, tests/test_pipeline.py:19-27); the HIP engines
+    are bf16-storage only, so a float16 / float32 request warns loudly and ``pipe.torch_dtype`` says what really runs."""
+    import torch
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline as P
+    for dt in (torch.float16, torch.float32):
+        with pytest.warns(UserWarning, match="runs in bfloat16"):
+            pipe = P.from_pretrained("tiny", torch_dtype=dt)
+        assert pipe.torch_dtype is torch.bfloat16 and pipe.requested_torch_dtype is dt
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert P.from_pretrained("tiny", torch_dtype=torch.bfloat16).torch_dtype is torch.bfloat16
+        assert P.from_pretrained("tiny").torch_dtype is torch.bfloat16
+    with pytest.raises(ValueError, match="unsupported torch_dtype"):
+        P.from_pretrained("tiny", torch_dtype=torch.int8)
+
+
 def test_frame_writer_renames_complete_files_into_place(tmp_path):
     from PIL import Image
     from stable_diffusion_videos_amd.utils import FrameWriter

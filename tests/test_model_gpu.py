@@ -342,6 +342,48 @@ CONFIG1_MIN = {"embeds_db": 50.5, "lat1_db": 54.0, "lat10_db": 49.0, "lat25_db":
                "frames_mean_abs": 1.5}
 
 
+def test_baseline_config5_fp8_50_steps_vs_golden(hip, dev, tmp_path):
+    """BASELINE.json configs[4] ("SD-v1-4 fp8 (CDNA4 fp8 MFMA)") on the config-1 fixture: ``from_pretrained(fp8=True)`` through
+    walk() - pilot calibration of the e4m3 activation scales, hipGraph capture, 50 steps, VAE, PNG files - against the fp32
+    oracle's frames.  Acceptance (stated before measuring, SURVEY.md 8c ladder step 4): frame PSNR >= 30 dB against the fp32
+    oracle; the measured PSNR, max / mean / p99 |d| on the uint8 image and the distance to the bf16 path's frames are reported.
+    Also the ADVICE r2 regression: the scales must come from the pilot run (identical for a second pipeline object, finite,
+    non-zero), not from the zero-filled graph warm-up."""
+    from PIL import Image
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline
+    d = np.load(Path(__file__).resolve().parent / "golden" / "config1_sd14_50steps.npz")
+    ref8 = d["frames_u8"]
+    frames = {}
+    for mode in ("fp8", "bf16"):
+        pipe = StableDiffusionWalkPipeline.from_pretrained("CompVis/stable-diffusion-v1-4", arch="sd14", fp8=mode == "fp8").to(dev)
+        assert pipe.use_graphs
+        pipe.walk(["a cat", "a dog"], seeds=[42, 1337], num_interpolation_steps=3, output_dir=str(tmp_path), name=mode,
+                  batch_size=3, make_video=False)
+        frames[mode] = np.stack([np.asarray(Image.open(tmp_path / mode / f"{mode}_000000" / f"frame{k:06d}.png")) for k in range(3)])
+        if mode == "fp8":
+            scales = pipe.unet.fp8_scales()
+            assert pipe.unet.fp8_calibrated and len(scales) == 22
+            assert all(np.isfinite(a) and np.isfinite(b) and a > 1e-4 and b > 1e-4 for a, b in scales)
+            # the pilot is prompt- / batch- / rank-independent: a direct call on different inputs leaves the scales alone
+            pipe(prompt="a horse", num_inference_steps=50, height=512, width=512, output_type="numpy_u8")
+            assert pipe.unet.fp8_scales() == scales
+        del pipe
+        torch.cuda.empty_cache()
+
+    def stats(a, b):
+        diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        mse = float((diff.astype(np.float64) ** 2).mean())
+        return 10 * np.log10(255.0 ** 2 / max(mse, 1e-12)), int(diff.max()), float(diff.mean()), int(np.percentile(diff, 99))
+
+    p8, mx8, mean8, p99_8 = stats(frames["fp8"], ref8)
+    p16, mx16, mean16, _ = stats(frames["bf16"], ref8)
+    p816, mx816, mean816, _ = stats(frames["fp8"], frames["bf16"])
+    report(f"config5 (fp8 ResBlock convs, 50 steps, 512x512, walk()): frames vs fp32 oracle PSNR {p8:.1f} dB, uint8 max|d| {mx8}, "
+           f"mean|d| {mean8:.3f}, p99|d| {p99_8}  (bf16 path: {p16:.1f} dB, max {mx16}, mean {mean16:.3f}); "
+           f"fp8 vs bf16 path {p816:.1f} dB, max {mx816}, mean {mean816:.3f}")
+    assert p8 >= 30.0
+
+
 def test_sd21_768_two_steps_with_audio_schedule(hip, dev):
     """BASELINE config 4 geometry (examples/make_music_video.py:43-55 call shape): SD-2.1 architecture at 768x768 (96x96
     latent, 9216-token self-attention with 64-wide heads, v-prediction, 1024-d text context), two interpolated frames whose
@@ -495,6 +537,28 @@ def test_rccl_weight_broadcast_path_runs_with_one_rank(hip, dev, tmp_path):
     outs = _run_ranks(1, "nccl", [str(rccl), "w"], extra_env={"SDV_DIST_INIT": "1"})
     assert "backend nccl done" in outs[0]
     assert _frames_of(plain / "w") == _frames_of(rccl / "w")
+
+
+def test_bench_launches_its_own_ranks(hip, dev):
+    """``python bench.py --gpus 2`` with no torchrun environment spawns two ranks itself and reports the group that formed
+    (here both on this box's one GPU, SDV_FORCE_DEVICE=0, so the collectives run over gloo - RCCL refuses two ranks on one
+    device); ``--gpus 8`` on this 1-GPU box must fail loudly instead of printing a 1-GPU line."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--arch", "tiny", "--steps", "1", "--warmup", "1",
+                        "--batch-size", "4", "--no-cpu-baseline", "--no-walk-pass", "--no-kernel-pass"],
+                       capture_output=True, text=True, env=dict(env, SDV_FORCE_DEVICE="0"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["config"]["frames"] == 2 * 4 and d["value"] > 0
+    if torch.cuda.device_count() < 8:
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode != 0 and not r.stdout.strip() and "refusing" in r.stderr
 
 
 def test_ragged_last_batch_reuses_the_captured_graph(hip, dev, tmp_path):

@@ -194,3 +194,100 @@ def test_clip_shape_table_matches_transformers_schema():
     shapes = clip_text_shapes(cfg)
     assert set(shapes) == set(sd) and all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
     assert count_params(clip_text_shapes(cfgs.sd14_text())) == 123_060_480      # CLIP ViT-L/14 text tower
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the third-party blocks (oracle/models.py) against a second, independent numpy-float64 restatement
+# (tests/golden/make_golden_blocks.py -> tests/golden/blocks_f64.npz) and against torch built-ins
+# ---------------------------------------------------------------------------------------------------------------------
+def _block_fixture(block):
+    z = np.load(GOLDEN / "blocks_f64.npz")
+    pre = block + "::"
+    params = {k[len(pre) + 3:]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith(pre + "p::")}
+    arrays = {k[len(pre):]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith(pre) and "::p::" not in k}
+    return params, arrays
+
+
+def _load(mod, params):
+    mod = mod.double().eval()
+    missing = mod.load_state_dict(params, strict=True)
+    return mod
+
+
+def test_timestep_embedding_closed_form():
+    """320-d sinusoids, [cos | sin] of t * exp(-ln(1e4) k / 160) - checked against the committed numpy
+    vectors AND a handful of closed-form values written out here."""
+    import math
+    z = np.load(GOLDEN / "blocks_f64.npz")
+    t = torch.from_numpy(z["temb::t"])
+    got = models.timestep_embedding(t, 320, True, 0)
+    assert np.allclose(got.numpy(), z["temb::flip"], atol=2e-4)          # (the oracle evaluates the angles in fp32)
+    assert abs(float(got[0, 0]) - math.cos(981.0)) < 1e-4 and abs(float(got[0, 160]) - math.sin(981.0)) < 1e-4
+    k = 7
+    f = math.exp(-math.log(10000.0) * k / 160)
+    assert abs(float(got[1, k]) - math.cos(501.0 * f)) < 1e-4 and abs(float(got[1, 160 + k]) - math.sin(501.0 * f)) < 1e-4
+    got = models.timestep_embedding(t, 32, False, 1)
+    assert np.allclose(got.numpy(), z["temb::noflip_shift1"], atol=2e-4)
+    p, a = _block_fixture("time_mlp")
+    m = _load(models.TimestepEmbedding(16, 24), p)
+    with torch.no_grad():
+        assert torch.allclose(m(a["x"]), a["y"], atol=1e-10)
+
+
+@pytest.mark.parametrize("name,cin,cout,temb", [("resnet_shortcut", 16, 24, 12), ("resnet_plain", 16, 16, 12), ("resnet_notemb", 16, 16, None)])
+def test_resnet_block_vs_independent_restatement(name, cin, cout, temb):
+    p, a = _block_fixture(name)
+    m = _load(models.ResnetBlock2D(cin, cout, temb, groups=8, eps=1e-5), p)
+    with torch.no_grad():
+        got = m(a["x"], a.get("temb"))
+    assert got.shape == a["y"].shape and float((got - a["y"]).abs().max()) < 1e-10
+
+
+@pytest.mark.parametrize("name,lin", [("transformer_conv", False), ("transformer_linear", True)])
+def test_transformer_block_vs_independent_restatement(name, lin):
+    """GroupNorm(eps 1e-6) -> proj_in -> self-attn / cross-attn / GEGLU FF with pre-LayerNorms -> proj_out -> + input: the
+    GEGLU chunk order (value = first half), the head split, the bias-free q/k/v, conv vs linear projections."""
+    p, a = _block_fixture(name)
+    m = _load(models.Transformer2DModel(heads=2, dim_head=8, channels=16, context_dim=12, groups=4, use_linear_projection=lin), p)
+    with torch.no_grad():
+        got = m(a["x"], a["ctx"])
+    assert float((got - a["y"]).abs().max()) < 1e-10
+    # the attention core against torch's own scaled_dot_product_attention
+    att = m.transformer_blocks[0].attn2
+    x = a["x"].permute(0, 2, 3, 1).reshape(2, 12, 16)
+    with torch.no_grad():
+        q = att.to_q(x).view(2, 12, 2, 8).transpose(1, 2)
+        k = att.to_k(a["ctx"]).view(2, 5, 2, 8).transpose(1, 2)
+        v = att.to_v(a["ctx"]).view(2, 5, 2, 8).transpose(1, 2)
+        sdpa = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2, 12, 16)
+        assert torch.allclose(att(x, a["ctx"]), att.to_out[0](sdpa), atol=1e-10)
+        # GEGLU = value * exact (erf) GELU of the gate
+        ff = m.transformer_blocks[0].ff.net[0]
+        h = ff.proj(x)
+        assert torch.allclose(ff(x), h[..., :64] * torch.nn.functional.gelu(h[..., 64:], approximate="none"), atol=1e-12)
+
+
+def test_samplers_and_vae_attention_vs_independent_restatement():
+    p, a = _block_fixture("downsample")
+    m = _load(models.Downsample2D(6), p)
+    with torch.no_grad():
+        assert float((m(a["x"]) - a["y"]).abs().max()) < 1e-10
+        p2, a2 = _block_fixture("downsample_odd")
+        assert m(a2["x"]).shape == a2["y"].shape == (2, 6, 3, 4) and float((m(a2["x"]) - a2["y"]).abs().max()) < 1e-10
+        pu, au = _block_fixture("upsample")
+        mu = _load(models.Upsample2D(6), pu)
+        assert float((mu(au["x"]) - au["y"]).abs().max()) < 1e-10
+        pv, av = _block_fixture("vae_attention")
+        mv = _load(models.VAEAttention(16, groups=4), pv)
+        assert float((mv(av["x"]) - av["y"]).abs().max()) < 1e-10
+
+
+def test_committed_block_vectors_are_what_the_generator_produces():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_blocks", GOLDEN / "make_golden_blocks.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fx = mod.build()
+    z = np.load(GOLDEN / "blocks_f64.npz")
+    assert set(fx) == set(z.files)
+    assert all(np.array_equal(fx[k], z[k]) for k in fx)
