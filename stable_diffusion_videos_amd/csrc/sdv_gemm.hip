@@ -75,12 +75,16 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     // tile's first MFMAs: with one workgroup per CU nothing else can cover those two latencies (they were 8-9 us of a 19 us
     // K = 320 tile, profiles/round2_gemm_overhead.txt), and the CUs stop moving through load / compute / store phases in
     // lockstep.  Every other tile runs this loop exactly once (grid = tiles).
-    constexpr bool PERSIST = NWV == 8 && NST == 2;
+    constexpr bool RING = NST > 2;
+    constexpr bool PERSIST = NWV == 8 && (!RING || !CONV);   // (ring tiles walk only as dense GEMMs - the short-K shapes they exist for)
     // LDS: NST K-slab buffers of SLOT bytes, then the epilogue's column vectors (3 x BN floats) and row accumulators.  The
     // epilogue's staging slabs (SLAB bytes per wave) alias the K-slab buffers - in a persistent workgroup the ONE slot the
     // tile's last K slab was read from, the other slot already receives the next tile.
     constexpr int SLAB = 32 * 144;   // 32 rows x (128 + 16 pad) bytes
-    constexpr int SLOT = PERSIST ? (TILE_BYTES > 2 * NWV * SLAB ? TILE_BYTES : 2 * NWV * SLAB) : TILE_BYTES;
+    // (ring tiles: ONE staging slab per wave, in the ring slot the tile's last K slab was read from - the other NST-1 slots
+    //  already hold the next tile's first K slabs)
+    constexpr int STG = (RING ? 1 : 2) * NWV * SLAB;
+    constexpr int SLOT = PERSIST ? (TILE_BYTES > STG ? TILE_BYTES : STG) : TILE_BYTES;
     // two slabs per wave (pass p+1 is parked while pass p is read back) wherever the K-slab buffers have the room
     constexpr bool DBL = (PERSIST ? SLOT : NST * SLOT) >= 2 * NWV * SLAB;
     static_assert(NST * SLOT >= NWV * SLAB, "the staging slabs must fit the K-slab buffers");
@@ -98,7 +102,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     // fill the 256-VGPR budget (they spilled 100-300 B of scratch per lane when simply hoisted out of the tile loop).
     int rg, pc;    // row inside the group one wave-instruction moves / physical 16-B chunk inside the LDS row
     int l31, lhi;
-    int xrow_off[TM], xrow_sw[TM], wrow_off[TN], wrow_sw[TN];   // LDS byte offsets of this lane's fragment rows (+ swizzle terms)
+    // Fragment reads: every 32-row MFMA tile of either panel starts on a multiple of 32 rows, so the row part of this lane's
+    // read address - l31 * ROWB - and its swizzle term - swz(l31) - are the SAME for all of them: one VGPR per k-step
+    // (frag_off[ks]) + a wave-uniform tile base, which ends up in the ds_read's immediate offset.  (An array of per-tile
+    // offsets + swizzles cost 2 x (TM + TN) VGPRs and 2-3 VALU per read.)
+    int frag_off[KSTEPS];
+    const int xrow0 = wm * TM * 32, wrow0 = BM + wn * TN * 32;   // first panel row of this wave's fragments (wave-uniform)
     auto swz = [](int r) { return ROWB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
 
     // addressing state of ONE tile (during a tile's last K slab it is re-pointed at the next tile)
@@ -110,6 +119,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     unsigned wvo[NW];          // lane byte offsets of the W rows relative to rs_w
     unsigned xvo[NX];
     int tap = 0, srcsel = 0, seg_left = 0;
+    bool dead_stream = false;   // ring tiles, last tile of a workgroup: the pieces past the tile's last K slab read nothing
     int kx = 0;   // scalar byte offset inside the current X source
     int kwb = 0;  // scalar byte offset along the W rows (all taps and sources are contiguous in K)
 
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         seg_left = 0;
         kx = 0;
         kwb = 0;
+        dead_stream = false;
     };
 
     // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
@@ -213,13 +224,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     vx = vx < 0 ? vx + ext_x : (vx >= ext_x ? vx - ext_x : vx);
                 }
                 const int iy = vy >> up_shift, ix = vx >> up_shift;
-                const bool ok = ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win) & (xr_[i] >= 0);
+                const bool ok = ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win) & (xr_[i] >= 0) & !dead_stream;
                 const int pix = xr_[i] + iy * p.Win + ix;
                 xvo[i] = ok ? (unsigned)(pix * ld2 + xlc[i]) : kOOB;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xvo[i] = xr_[i] >= 0 ? (unsigned)(xr_[i] * ld2 + xlc[i]) : kOOB;
+            for (int i = 0; i < NX; ++i) xvo[i] = (xr_[i] >= 0 && !dead_stream) ? (unsigned)(xr_[i] * ld2 + xlc[i]) : kOOB;
         }
         kx = 0;
         seg_left = (srcsel ? K - p.C1 : p.C1) / BK;
@@ -267,18 +278,11 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         pc = lk % CPRW;
         l31 = lk & 31;
         lhi = lk >> 5;
+        static_assert(BM % 32 == 0, "fragment tiles start on multiples of 32 rows (the swizzle term depends on l31 only)");
+        // logical chunk of k-step ks: bf16 tiles 2 ks + lhi (16 bytes = 8 elements); fp8 tiles read chunk 2 j + lhi for the
+        // k-step PAIR j (see compute) - the same expression with ks = j
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int r = wm * TM * 32 + mt * 32 + l31;
-            xrow_off[mt] = r * ROWB;
-            xrow_sw[mt] = swz(r);
-        }
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-            const int r = BM + wn * TN * 32 + nt * 32 + l31;
-            wrow_off[nt] = r * ROWB;
-            wrow_sw[nt] = swz(r);
-        }
+        for (int ks = 0; ks < KSTEPS; ++ks) frag_off[ks] = l31 * ROWB + (((ks * 2 + lhi) ^ swz(l31)) << 4);
     };
 
     // Software-pipelined K tile: the fragments of k-step ks+1 are read into a second register set while the
@@ -293,11 +297,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             typedef __attribute__((ext_vector_type(2))) long long i64x2_t;
             i64x2_t xq[2][TM], wq[2][TN];
             auto load_q = [&](int j, i64x2_t* xd, i64x2_t* wd) {
-                const int lc = j * 2 + lhi;
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const i64x2_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
+                for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const i64x2_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[j]);
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const i64x2_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+                for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const i64x2_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[j]);
             };
             load_q(0, xq[0], wq[0]);
             load_q(1, xq[1], wq[1]);
@@ -317,11 +320,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 bf16x8_t xs[TM], ws[TN];
-                const int lc = ks * 2 + lhi;
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) xs[mt] = *(const bf16x8_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
+                for (int mt = 0; mt < TM; ++mt) xs[mt] = *(const bf16x8_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[ks]);
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) ws[nt] = *(const bf16x8_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+                for (int nt = 0; nt < TN; ++nt) ws[nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[ks]);
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
@@ -332,11 +334,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         }
         bf16x8_t xf[2][TM], wf[2][TN];
         auto load_frags = [&](int ks, bf16x8_t* xd, bf16x8_t* wd) {
-            const int lc = ks * 2 + lhi;
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
+            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[ks]);
 #pragma unroll
-            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[ks]);
         };
         load_frags(0, xf[0], wf[0]);
 #pragma unroll
@@ -365,6 +366,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     int slot0 = 0;
     bool landed = false;
     bool has_next = false;
+    int cb = 0;         // ring tiles: slot of the K slab being computed - the ring keeps turning across tiles
+    int cb_stage = 0;   //             slot the tile's LAST slab was read from = where its epilogue stages
     auto kloop = [&]() {
     if constexpr (NST > 2) {
         // ---- ring main loop ------------------------------------------------------------------------------
@@ -373,10 +376,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         static_assert(GX % NWV == 0, "ring tiles: X panel pieces must divide evenly over the waves");
         auto issue_pieces = [&](char* base) {
             const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
+            // (the K positions are wave-uniform by construction; said explicitly, because once they travel around the persistent
+            //  tile loop the compiler's uniformity analysis gives up and wraps every piece in a waterfall loop - guide T20)
+            const int kx_s = __builtin_amdgcn_readfirstlane(kx), kwb_s = __builtin_amdgcn_readfirstlane(kwb);
 #pragma unroll
             for (int i = 0; i < NX; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(base + (wave + NWV * i) * 1024),
-                                                         16, (int)xvo[i], kx, 0, 0);
+                                                         16, (int)xvo[i], kx_s, 0, 0);
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 int g = wave + NWV * i;
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     off = dup ? wvo[i > 0 ? i - 1 : 0] : off;
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024), 16,
-                                                         (int)off, kwb, 0, 0);
+                                                         (int)off, kwb_s, 0, 0);
             }
         };
         auto advance = [&]() {   // K-position bookkeeping of the piece stream (kept out of the MFMA blocks: it branches)
@@ -418,11 +424,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         };
         bf16x8_t fax[TM], faw[TN], fbx[TM], fbw[TN];
         auto read_frags = [&](const char* base, int ks, bf16x8_t* xd, bf16x8_t* wd) {
-            const int lc = ks * 2 + lhi;
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + xrow_off[mt] + ((lc ^ xrow_sw[mt]) << 4));
+            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[ks]);
 #pragma unroll
-            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + wrow_off[nt] + ((lc ^ wrow_sw[nt]) << 4));
+            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[ks]);
         };
         auto mfmas = [&](const bf16x8_t* xs, const bf16x8_t* ws) {
 #pragma unroll
@@ -431,20 +436,46 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 for (int mt = 0; mt < TM; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[nt], xs[mt], acc[nt][mt], 0, 0, 0);
         };
-        // prologue: fill the ring, wait for tile 0, fetch its first fragments
-        const int npre = nkt < NST ? nkt : NST;
-        for (int s = 0; s < npre; ++s) issue_all(smem + s * TILE_BYTES);
-        if (npre >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * PER) : "memory");
-        else wait_stages(npre - 1);
-        __builtin_amdgcn_s_barrier();
-        read_frags(smem, 0, fax, faw);
-        int cb = 0;   // ring slot of the tile being computed
+        auto slot_at = [&](int sl) { return smem + sl * SLOT; };
+        // Prologue.  First tile of a workgroup: fill the ring, wait for K slab 0.  Later tiles of a PERSISTENT workgroup: the
+        // ring never stopped - K slabs 0 .. NST-2 of this tile were issued behind the last NST-1 slabs of the tile before (and
+        // waited for ahead of its epilogue, so nothing this tile reads early queues behind that epilogue's stores); only their
+        // bookkeeping is replayed here, and slab NST-1 goes into the slot the epilogue staged in as soon as every wave has read
+        // its staging slab back.  (The host launches ring tiles persistently only when a tile has >= NST K slabs.)
+        // (the stream of pieces NEVER thins out: where no K slab is left to fetch - the tail of a workgroup's last tile, tiles
+        //  with fewer than NST slabs - it carries "dead" pieces whose offsets lie outside the buffers: the range check answers
+        //  them with zeros without touching memory, they land in a slot nobody reads any more, and every counted wait in the loop
+        //  stays the same constant)
+        auto go_dead = [&]() {
+            dead_stream = true;
+            seg_left = 0;          // -> new_segment() at the next issue, which now writes out-of-range offsets
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wvo[i] = kOOB;
+        };
+        if (!(PERSIST && landed)) {
+#pragma nounroll
+            for (int sl = 0; sl < NST; ++sl) {
+                if (sl == nkt) go_dead();
+                issue_all(slot_at(sl));
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * PER) : "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            for (int sl = 0; sl + 1 < NST; ++sl) {
+                if (seg_left == 0) new_segment();
+                advance();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_all(slot_at(cb_stage));
+        }
+        read_frags(slot_at(cb), 0, fax, faw);
         // One K tile: [k-step 0 MFMAs || fragment reads of k-step 1] -> counted wait + barrier (tile kt+1 is now visible to
         // every wave and nobody reads tile kt from LDS any more) -> [k-step 1 MFMAs || fragment reads of tile kt+1 ||
         // LDS-DMA of tile kt+NST into the slot tile kt just left].
         auto body = [&](auto ISSUE, auto NEXT, int ahead) {
             constexpr bool issue = decltype(ISSUE)::value, next = decltype(NEXT)::value;
-            const char* cur = smem + cb * TILE_BYTES;
+            const char* cur = slot_at(cb);
             read_frags(cur, 1, fbx, fbw);
             mfmas(fax, faw);
 #pragma unroll
@@ -459,8 +490,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 const int nb = cb + 1 == NST ? 0 : cb + 1;
                 if constexpr (issue)
                     if (seg_left == 0) new_segment();
-                read_frags(smem + nb * TILE_BYTES, 0, fax, faw);
-                if constexpr (issue) issue_pieces(smem + cb * TILE_BYTES);
+                read_frags(slot_at(nb), 0, fax, faw);
+                if constexpr (issue) issue_pieces(slot_at(cb));
                 mfmas(fbx, fbw);
 #pragma unroll
                 // (the LDS-DMA pieces write LDS, so the compiler keeps them behind the fragment reads: reads go behind the
@@ -483,10 +514,28 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 mfmas(fbx, fbw);
             }
         };
-        int kt = 0;
-        for (; kt + NST < nkt; ++kt) body(std::true_type{}, std::true_type{}, NST - 2);
-        for (; kt + 1 < nkt; ++kt) body(std::false_type{}, std::true_type{}, nkt - kt - 2);
+        // ONE instance of the steady-state body, always issuing PER pieces (so every counted wait is the same constant): slabs
+        // kt + NST of this tile, then - persistent workgroups - slabs 0 .. NST-2 of the NEXT tile (the addressing is re-pointed
+        // between the two runs of the loop), or, for the last tile of a workgroup, pieces whose offsets lie outside the buffers
+        // (the range check answers them with zeros without touching memory; the slot they land in is dead).  The tile's last
+        // slab issues nothing: its slot is the epilogue's staging area.
+        {
+            int kt = 0;
+            const int kswitch = nkt > NST ? nkt - NST : 0;
+#pragma nounroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int kend = ph == 0 ? kswitch : nkt - 1;
+#pragma nounroll
+                for (; kt < kend; ++kt) body(std::true_type{}, std::true_type{}, NST - 2);
+                if (ph == 0) {
+                    if (PERSIST && has_next) setup_tile(vb + (int)gridDim.x);
+                    else if (!dead_stream) go_dead();
+                }
+            }
+        }
         body(std::false_type{}, std::false_type{}, 0);
+        cb_stage = cb;
+        cb = cb + 1 == NST ? 0 : cb + 1;
     } else {
     // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
     // The barriers here are RAW (own LDS reads retired + s_barrier): __syncthreads() is lowered to s_waitcnt vmcnt(0) +
@@ -572,7 +621,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             //  read back as 16-byte pieces in another, and type-based alias analysis must not reorder the two)
             typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) slab_u4;
             typedef unsigned int __attribute__((ext_vector_type(2), may_alias)) slab_u2;
-            char* const stg_region = PERSIST ? smem + ((slot0 + nkt - 1) & 1) * SLOT : smem;
+            char* const stg_region = !PERSIST ? smem : (RING ? smem + cb_stage * SLOT : smem + ((slot0 + nkt - 1) & 1) * SLOT);
             char* const slab0 = stg_region + wave * (DBL ? 2 : 1) * SLAB;
             auto slab_of = [&](int pi) { return slab0 + (DBL ? (pi & 1) * SLAB : 0); };
             // Per-column epilogue vectors of this tile's BN columns, staged in LDS ONCE per tile (their own region behind the
@@ -624,7 +673,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 }
                 // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
                 // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
-                if (PERSIST && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (ring tiles: always - the dead pieces behind a workgroup's last slab must have landed before the staging slot is
+                //  written and before the workgroup gives its LDS back)
+                if (RING || (PERSIST && has_next)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (i < BN) {
                     vbias[i] = vb_;
                     if constexpr (lnsd == 1) vaux[i] = vs_;
@@ -930,7 +981,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     }
 
     // ---- fallback epilogue straight from the MFMA registers (odd leading dims / N, e.g. the 77-token V^T) ----
-    if (PERSIST && has_next) {   // (as above: the next tile's first slab is waited for here)
+    if (RING || (PERSIST && has_next)) {   // (as above: the next tile's first slab is waited for here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1101,8 +1152,8 @@ template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT =
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int TILE_BYTES = (BM + BN) * BK * (FEAT == 8 ? 1 : 2);
-    constexpr bool PERSIST = WM * WN == 8 && NST == 2;                 // (see the kernel)
-    constexpr int SLABS = 2 * WM * WN * 32 * 144;                      // the epilogue's staging slabs (alias ONE K-slab buffer)
+    constexpr bool PERSIST = WM * WN == 8 && (NST == 2 || !CONV);      // (see the kernel)
+    constexpr int SLABS = (NST > 2 ? 1 : 2) * WM * WN * 32 * 144;      // the epilogue's staging slabs (alias ONE K-slab buffer)
     constexpr int SLOT = PERSIST && SLABS > TILE_BYTES ? SLABS : TILE_BYTES;
     constexpr int LDS = NST * SLOT + 3 * BN * 4 + WM * WN * 256;       // K-slab buffers + column vectors + row-stat accumulators
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
@@ -1116,7 +1167,10 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const long long total = (long long)tiles_m * tiles_n * (a.batch > 0 ? a.batch : 1);
     SDV_REQUIRE(total < 0x7fffffffLL, "sdv_gemm_bf16: too many tiles");
-    dim3 grid((unsigned)(PERSIST && g_persistent && total > num_cus() ? num_cus() : total), 1, 1);
+    // (a ring tile's workgroup walks tiles only when every tile has at least NST K slabs: the stream runs NST-1 slabs ahead)
+    const long long nkt = (long long)(a.K / BK) * (CONV ? (a.mode == 4 ? 4 : 9) : 1);
+    const bool walk = PERSIST && g_persistent && total > num_cus() && (NST == 2 || nkt >= NST);
+    dim3 grid((unsigned)(walk ? num_cus() : total), 1, 1);
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>), grid, dim3(WM * WN * 64), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
@@ -1128,7 +1182,7 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
 template <int WM, int WN, int TM, int TN, int BK, int NST = 2, bool LN_OK = false, bool LN2_OK = LN_OK>
 int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
     if (a.fp8) {
-        if constexpr (LN_OK) {   // the same four 8-wave / 4-wave tiles carry the fp8 variants
+        if constexpr (LN_OK && BK == 64 && NST == 2) {   // the same four 8-wave / 4-wave tiles carry the fp8 variants
             SDV_REQUIRE(!a.ln_side && !a.stats_out, "sdv_gemm_bf16: fp8 operands do not combine with the LayerNorm fold");
             return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 8>(a, stream)
                                : launch_igemm_t<WM, WN, TM, TN, BK, true, NST, 8>(a, stream);
@@ -1302,7 +1356,7 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         case 11: return launch_igemm<4, 1, 2, 2, 64>(a, s);   // 256 x  64, 4 waves
 #endif
 #ifndef SDV_GEMM_ONLY_TILE6
-        case 12: return launch_igemm<4, 2, 2, 5, 32, 4>(a, s);   // 256 x 320, 8 waves, ring of four 32-wide K tiles
+        case 12: return launch_igemm<4, 2, 2, 5, 32, 4, true, false>(a, s);   // 256 x 320, 8 waves, PERSISTENT ring of four 32-wide K tiles
         case 13: return launch_igemm<4, 2, 2, 4, 32, 4>(a, s);   // 256 x 256, 8 waves, ring
 #endif
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
