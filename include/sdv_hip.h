@@ -221,6 +221,20 @@ int sdv_lerp_batch(const float* a, const float* b, const float* T, int32_t nfram
 int sdv_cfg_ddim_step(const float* eps, float* latents, sdv_bf16* x2, const float* coefs,
                       const int32_t* step_ptr, const float* noise, float guidance, int32_t cfg,
                       int64_t n_per_batch /* B*HW*C */, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * The same for every OTHER scheduler the reference's constructor accepts (stable_diffusion_pipeline.py:71-78 - PNDM/PLMS
+ * (the SD-v1 default), LMSDiscrete (examples/make_music_video.py:15), EulerDiscrete, EulerAncestral, DPM-Solver++ 2M):
+ * `scheduler.scale_model_input` (:415), guidance (:422-423) and `scheduler.step(...).prev_sample` (:426) of ONE UNet
+ * evaluation.  All of them are linear in (sample, model outputs), so the host precomputes one row per evaluation:
+ *     table[step][16] = { a, c, w0, w1, w2, w3, u, v, s_in, s_noise, flags, head, 0, 0, 0, 0 }
+ *     g = eps_u + guidance (eps_c - eps_u);   m = u x + v g;   comb = w0 m + w1 H[head-1] + w2 H[head-2] + w3 H[head-3]
+ *     x' = a (flags & 4 ? xsave : x) + c comb (+ s_noise noise[step]);   flags & 2: xsave = x;   flags & 1: H[head] = m
+ *     x2 = bf16(s_in x') for both CFG halves (the NEXT evaluation's scaled model input)
+ * hist: fp32 [4][n] ring (indices mod 4), xsave: fp32 [n]; eps / latents / x2 / noise as for sdv_cfg_ddim_step.
+ * ------------------------------------------------------------------------------------------ */
+int sdv_cfg_multistep_step(const float* eps, float* latents, sdv_bf16* x2, float* hist, float* xsave, const float* table,
+                           const int32_t* step_ptr, const float* noise, float guidance, int32_t cfg,
+                           int64_t n_per_batch /* B*HW*C */, void* stream);
 /* latents fp32 -> bf16 UNet input (both CFG halves); used once before step 0 */
 int sdv_latents_to_unet_input(const float* latents, sdv_bf16* x2, int32_t cfg, int64_t n, void* stream);
 int sdv_step_counter_add(int32_t* step_ptr, int32_t inc, void* stream);

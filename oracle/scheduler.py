@@ -73,3 +73,218 @@ class DDIMScheduler:
                 variance_noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
             prev = prev + std * variance_noise
         return prev
+
+
+# ======================================================================================================================
+# The other schedulers the reference's constructor accepts (stable_diffusion_pipeline.py:71-78): restated in their CLASSIC,
+# stateful form from the published algorithms as diffusers ~0.11-0.14 implements them (the un-vendored dependency; **parity
+# unpinned**).  The product (stable_diffusion_videos_amd/scheduler.py) does NOT step like this: it turns every one of them into a
+# per-step table of linear coefficients for one fused kernel - the tests step both on the same model outputs.
+#   PNDMScheduler (skip_prk_steps=True, the SD-v1 default: PLMS, Liu et al. 2022 eq. 9 + the 4-step Adams-Bashforth weights;
+#       diffusers' warm-up re-evaluates the second timestep, so N steps cost N + 1 UNet calls)
+#   LMSDiscreteScheduler / EulerDiscreteScheduler / EulerAncestralDiscreteScheduler (Karras et al. 2022 sigma space, k-diffusion)
+#   DPMSolverMultistepScheduler (DPM-Solver++ 2M, Lu et al. 2022, midpoint form)
+# ======================================================================================================================
+def _betas(num_train_timesteps, beta_start, beta_end, beta_schedule):
+    if beta_schedule == "scaled_linear":
+        return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    if beta_schedule == "linear":
+        return torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+    raise NotImplementedError(beta_schedule)
+
+
+class PNDMScheduler:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1, prediction_type="epsilon"):
+        assert skip_prk_steps, "the SD checkpoints ship skip_prk_steps=True (PLMS only)"
+        self.alphas_cumprod = torch.cumprod(1.0 - _betas(num_train_timesteps, beta_start, beta_end, beta_schedule), dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_train_timesteps, self.steps_offset, self.prediction_type = num_train_timesteps, steps_offset, prediction_type
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        base = (np.arange(0, num_inference_steps) * ratio).round() + self.steps_offset
+        plms = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+        self.timesteps = torch.from_numpy(plms.astype(np.int64))
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        if self.prediction_type == "v_prediction":
+            model_output = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return sample_coeff * sample - (a_p - a_t) * model_output / denom
+
+    def step(self, model_output, timestep, sample, **_):
+        timestep = int(timestep)
+        prev_timestep = timestep - self.num_train_timesteps // self.num_inference_steps
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep = timestep
+            timestep = timestep + self.num_train_timesteps // self.num_inference_steps
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        prev = self._get_prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return prev
+
+
+class _KarrasSigmaBase:
+    """Shared set-up of the sigma-space schedulers: sigma_t = sqrt((1 - abar_t) / abar_t), float timesteps on a linspace."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="epsilon"):
+        self.alphas_cumprod = torch.cumprod(1.0 - _betas(num_train_timesteps, beta_start, beta_end, beta_schedule), dim=0)
+        self.num_train_timesteps, self.prediction_type = num_train_timesteps, prediction_type
+        s = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.init_noise_sigma = float(s.max())
+        self.set_timesteps(num_train_timesteps)
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = num_inference_steps
+        ts = np.linspace(0, self.num_train_timesteps - 1, num_inference_steps, dtype=float)[::-1].copy()
+        s = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        s = np.interp(ts, np.arange(0, len(s)), s)
+        self.sigmas = torch.from_numpy(np.concatenate([s, [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+        self.derivatives = []
+
+    def _index(self, timestep):
+        return int((self.timesteps == float(timestep)).nonzero()[0])
+
+    def scale_model_input(self, sample, timestep):
+        sigma = self.sigmas[self._index(timestep)]
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def _pred_original(self, model_output, sample, sigma):
+        if self.prediction_type == "epsilon":
+            return sample - sigma * model_output
+        if self.prediction_type == "v_prediction":
+            return model_output * (-sigma / (sigma ** 2 + 1) ** 0.5) + sample / (sigma ** 2 + 1)
+        raise NotImplementedError(self.prediction_type)
+
+
+class LMSDiscreteScheduler(_KarrasSigmaBase):
+    def get_lms_coefficient(self, order, t, current_order):
+        from scipy import integrate
+
+        def lms_derivative(tau):
+            prod = 1.0
+            for k in range(order):
+                if current_order == k:
+                    continue
+                prod *= (tau - self.sigmas[t - k]) / (self.sigmas[t - current_order] - self.sigmas[t - k])
+            return prod
+
+        return integrate.quad(lms_derivative, float(self.sigmas[t]), float(self.sigmas[t + 1]), epsrel=1e-4)[0]
+
+    def step(self, model_output, timestep, sample, order=4, **_):
+        i = self._index(timestep)
+        sigma = self.sigmas[i]
+        derivative = (sample - self._pred_original(model_output, sample, sigma)) / sigma
+        self.derivatives.append(derivative)
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(i + 1, order)
+        coeffs = [self.get_lms_coefficient(order, i, k) for k in range(order)]
+        return sample + sum(c * d for c, d in zip(coeffs, reversed(self.derivatives)))
+
+
+class EulerDiscreteScheduler(_KarrasSigmaBase):
+    def step(self, model_output, timestep, sample, **_):
+        i = self._index(timestep)
+        sigma = self.sigmas[i]
+        derivative = (sample - self._pred_original(model_output, sample, sigma)) / sigma
+        return sample + derivative * (self.sigmas[i + 1] - sigma)
+
+
+class EulerAncestralDiscreteScheduler(_KarrasSigmaBase):
+    def step(self, model_output, timestep, sample, generator=None, variance_noise=None, **_):
+        i = self._index(timestep)
+        sigma_from, sigma_to = self.sigmas[i], self.sigmas[i + 1]
+        sigma_up = (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5
+        sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+        derivative = (sample - self._pred_original(model_output, sample, sigma_from)) / sigma_from
+        prev = sample + derivative * (sigma_down - sigma_from)
+        if variance_noise is None:
+            variance_noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
+        return prev + variance_noise * sigma_up
+
+
+class DPMSolverMultistepScheduler:
+    """DPM-Solver++ (2M): data-prediction, second-order multistep, midpoint form."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 solver_order=2, prediction_type="epsilon", lower_order_final=True):
+        assert solver_order in (1, 2)
+        ac = torch.cumprod(1.0 - _betas(num_train_timesteps, beta_start, beta_end, beta_schedule), dim=0)
+        self.alphas_cumprod = ac
+        self.alpha_t, self.sigma_t = ac ** 0.5, (1 - ac) ** 0.5
+        self.lambda_t = torch.log(self.alpha_t) - torch.log(self.sigma_t)
+        self.init_noise_sigma = 1.0
+        self.num_train_timesteps, self.solver_order, self.prediction_type = num_train_timesteps, solver_order, prediction_type
+        self.lower_order_final = lower_order_final
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = num_inference_steps
+        ts = np.linspace(0, self.num_train_timesteps - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts)
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums = 0
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _convert(self, model_output, timestep, sample):
+        a, s = self.alpha_t[timestep], self.sigma_t[timestep]
+        if self.prediction_type == "epsilon":
+            return (sample - s * model_output) / a
+        if self.prediction_type == "v_prediction":
+            return a * sample - s * model_output
+        raise NotImplementedError(self.prediction_type)
+
+    def step(self, model_output, timestep, sample, **_):
+        timestep = int(timestep)
+        i = int((self.timesteps == timestep).nonzero()[0])
+        prev_t = 0 if i == len(self.timesteps) - 1 else int(self.timesteps[i + 1])
+        lower_final = (i == len(self.timesteps) - 1) and self.lower_order_final and len(self.timesteps) < 15
+        x0 = self._convert(model_output, timestep, sample)
+        for k in range(self.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = x0
+        lt, ls = self.lambda_t[prev_t], self.lambda_t[timestep]
+        at, st, ss = self.alpha_t[prev_t], self.sigma_t[prev_t], self.sigma_t[timestep]
+        h = lt - ls
+        if self.solver_order == 1 or self.lower_order_nums < 1 or lower_final:
+            prev = (st / ss) * sample - at * (torch.exp(-h) - 1.0) * x0
+        else:
+            s1 = int(self.timesteps[i - 1])
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            h0 = ls - self.lambda_t[s1]
+            r0 = h0 / h
+            d1 = (1.0 / r0) * (m0 - m1)
+            prev = (st / ss) * sample - at * (torch.exp(-h) - 1.0) * m0 - 0.5 * at * (torch.exp(-h) - 1.0) * d1
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        return prev

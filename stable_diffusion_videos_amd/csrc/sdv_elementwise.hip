@@ -17,7 +17,7 @@ void sdv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sdv_last_error(void) { return g_err; }
-extern "C" int sdv_abi_version(void) { return 5; }
+extern "C" int sdv_abi_version(void) { return 6; }
 
 namespace {
 
@@ -132,6 +132,56 @@ __global__ __launch_bounds__(kThreads) void cfg_ddim_kernel(const float* __restr
         const uint16_t xb = f32_to_bf16(x);
         x2[i] = xb;
         if (cfg) x2[n + i] = xb;
+    }
+}
+
+// ---- CFG + linear multistep update (PNDM/PLMS, LMS, Euler, Euler-ancestral, DPM-Solver++ 2M) -----------------------------
+// Every scheduler the reference accepts (stable_diffusion_pipeline.py:71-78) advances the latents by a LINEAR combination of
+// the current sample, the current model output and up to three earlier ones; the host (scheduler.py) precomputes one row of
+// coefficients per UNet evaluation (layout in sdv_hip.h) and this kernel is the whole of scheduler.step() + the next
+// scale_model_input() + torch.cat([latents] * 2):
+//     g    = eps_u + guidance (eps_c - eps_u)                      classifier-free guidance (:422-423)
+//     m    = u x + v g                                            model output in the solver's variable (eps, x0 or dx/dsigma)
+//     comb = w0 m + w1 H[-1] + w2 H[-2] + w3 H[-3]                H = ring of the m of earlier evaluations
+//     x'   = a x_base + c comb (+ sn noise)                       x_base = x, or the sample saved at PLMS's first evaluation
+//     x2   = bf16(s_in x')                                        the next UNet input, both CFG halves
+__global__ __launch_bounds__(kThreads) void cfg_multistep_kernel(const float* __restrict__ eps, float* __restrict__ latents,
+                                                                 uint16_t* __restrict__ x2, float* __restrict__ hist,
+                                                                 float* __restrict__ xsave, const float* __restrict__ table,
+                                                                 const int* __restrict__ step_ptr, const float* __restrict__ noise,
+                                                                 float guidance, int cfg, long long n) {
+    const int step = step_ptr ? *step_ptr : 0;
+    const float* r = table + (long long)step * 16;
+    const float a = r[0], c = r[1], w0 = r[2], w1 = r[3], w2 = r[4], w3 = r[5], u = r[6], v = r[7], s_in = r[8], sn = r[9];
+    const int flags = (int)r[10], head = (int)r[11];
+    const bool push = flags & 1, save = flags & 2, use_saved = flags & 4;
+    const float* h1 = hist + (long long)((head + 3) & 3) * n;
+    const float* h2 = hist + (long long)((head + 2) & 3) * n;
+    const float* h3 = hist + (long long)((head + 1) & 3) * n;
+    float* hp = hist + (long long)(head & 3) * n;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        float g;
+        if (cfg) {
+            const float eu = eps[i], ec = eps[n + i];
+            g = eu + guidance * (ec - eu);
+        } else {
+            g = eps[i];
+        }
+        const float xc = latents[i];
+        const float m = u * xc + v * g;
+        float comb = w0 * m;
+        if (w1 != 0.f) comb += w1 * h1[i];
+        if (w2 != 0.f) comb += w2 * h2[i];
+        if (w3 != 0.f) comb += w3 * h3[i];
+        const float xb = use_saved ? xsave[i] : xc;
+        if (save) xsave[i] = xc;
+        float x = a * xb + c * comb;
+        if (noise && sn != 0.f) x += sn * noise[(long long)step * n + i];
+        latents[i] = x;
+        if (push) hp[i] = m;
+        const uint16_t xq = f32_to_bf16(x * s_in);
+        x2[i] = xq;
+        if (cfg) x2[n + i] = xq;
     }
 }
 
@@ -476,6 +526,16 @@ extern "C" int sdv_cfg_ddim_step(const float* eps, float* latents, sdv_bf16* x2,
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n_per_batch, kThreads, 2048)), dim3(kThreads), 0,
                        (hipStream_t)stream, eps, latents, x2, coefs, step_ptr, noise, guidance, cfg, (long long)n_per_batch);
     SDV_CHECK_LAUNCH("sdv_cfg_ddim_step");
+    return SDV_OK;
+}
+
+extern "C" int sdv_cfg_multistep_step(const float* eps, float* latents, sdv_bf16* x2, float* hist, float* xsave,
+                                      const float* table, const int32_t* step_ptr, const float* noise, float guidance,
+                                      int32_t cfg, int64_t n_per_batch, void* stream) {
+    SDV_REQUIRE(eps && latents && x2 && hist && xsave && table && n_per_batch > 0, "sdv_cfg_multistep_step: bad args");
+    hipLaunchKernelGGL(cfg_multistep_kernel, dim3(grid_for(n_per_batch, kThreads, 2048)), dim3(kThreads), 0, (hipStream_t)stream,
+                       eps, latents, x2, hist, xsave, table, step_ptr, noise, guidance, cfg, (long long)n_per_batch);
+    SDV_CHECK_LAUNCH("sdv_cfg_multistep_step");
     return SDV_OK;
 }
 

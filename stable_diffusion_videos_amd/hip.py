@@ -41,7 +41,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 5     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 6     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "sdv_slerp_batch": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
     "sdv_lerp_batch": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdv_cfg_ddim_step": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_int64, C.c_void_p]),
+    "sdv_cfg_multistep_step": (C.c_int, [C.c_void_p] * 8 + [C.c_float, C.c_int32, C.c_int64, C.c_void_p]),
     "sdv_latents_to_unet_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "sdv_step_counter_add": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "sdv_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
@@ -497,6 +498,14 @@ def cfg_ddim_step(eps, latents, x2, coefs, step_ptr, noise, guidance: float, cfg
     _check(lib.sdv_cfg_ddim_step(_ptr(eps, F32), _ptr(latents, F32), _ptr(x2, BF16), _ptr(coefs, F32),
                                  _ptr(step_ptr, torch.int32), _ptr(noise, F32), guidance, int(cfg), n, _stream()),
            "sdv_cfg_ddim_step")
+
+
+def cfg_multistep_step(eps, latents, x2, hist, xsave, table, step_ptr, noise, guidance: float, cfg: bool, n: int):
+    """One fused guidance + linear-multistep scheduler update (sdv_hip.h: every scheduler besides DDIM)."""
+    lib = load()
+    _check(lib.sdv_cfg_multistep_step(_ptr(eps, F32), _ptr(latents, F32), _ptr(x2, BF16), _ptr(hist, F32), _ptr(xsave, F32),
+                                      _ptr(table, F32), _ptr(step_ptr, torch.int32), _ptr(noise, F32), guidance, int(cfg), n,
+                                      _stream()), "sdv_cfg_multistep_step")
 
 
 def latents_to_unet_input(latents, x2, cfg: bool, n: int):

@@ -40,7 +40,7 @@ import torch
 from . import config as cfgs
 from . import hip, parallel, weights
 from .engine import UNetEngine, VAEDecoderEngine
-from .scheduler import DDIMScheduler
+from .scheduler import DDIMScheduler, adopt as adopt_scheduler
 from .text import build_text_encoder, load_tokenizer
 from .utils import FrameWriter, get_timesteps_arr, make_video_pyav, numpy_to_pil
 
@@ -68,6 +68,31 @@ class _PendingModule:
             self.in_channels = config.in_channels
 
 
+class _ForeignVAE:
+    """Adapter for a ``vae=`` object that is not one of this package's engines (the reference forwards ``vae=`` to diffusers:
+    examples/make_music_video.py:14 passes a fine-tuned AutoencoderKL).  Anything with ``decode(z)`` returning a tensor or an
+    object with ``.sample`` (NCHW, roughly [-1, 1]) works; it runs wherever that object lives - the HIP decoder is bypassed,
+    the image epilogue (:432-438 and numpy_to_pil's rounding) is done here."""
+
+    def __init__(self, vae):
+        self.inner = vae
+        cfg = getattr(vae, "config", None)
+        get = (lambda k, d: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d: getattr(cfg, k, d))
+        self.config = SimpleNamespace(block_out_channels=tuple(get("block_out_channels", (128, 256, 512, 512))),
+                                      scaling_factor=float(get("scaling_factor", 0.18215)))
+
+    def decode(self, latents: torch.Tensor, want_float: bool = False):
+        z = latents.permute(0, 3, 1, 2) / self.config.scaling_factor                           # NHWC fp32 -> NCHW, :432
+        p = next(iter(self.inner.parameters()), None) if hasattr(self.inner, "parameters") else None
+        if p is not None:
+            z = z.to(p.device, p.dtype)
+        out = self.inner.decode(z)
+        img = out.sample if hasattr(out, "sample") else (out[0] if isinstance(out, (tuple, list)) else out)
+        f32 = (img.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous()             # :435-438
+        u8 = (f32 * 255).round().to(torch.uint8)
+        return u8.to(latents.device), (f32.to(latents.device) if want_float else None)
+
+
 class StableDiffusionWalkPipeline:
     _optional_components = ["safety_checker", "feature_extractor"]
 
@@ -77,6 +102,9 @@ class StableDiffusionWalkPipeline:
             raise ValueError("Make sure to define a feature extractor when loading StableDiffusionWalkPipeline if you "
                              "want to use the safety checker. If you do not want to use the safety checker, you can "
                              "pass `'safety_checker=None'` instead.")
+        # a diffusers scheduler object of a known class (DDIM / PNDM / LMS / Euler / EulerA / DPM-Solver++) is rebuilt as the
+        # table-driven scheduler of the same name from its config; anything else raises here, not in the middle of a walk
+        scheduler = adopt_scheduler(scheduler)
         # the two config patches the reference applies to the scheduler (:85-110)
         if getattr(scheduler.config, "steps_offset", 1) != 1:
             scheduler.config.steps_offset = 1
@@ -165,12 +193,20 @@ class StableDiffusionWalkPipeline:
                 u_sd = v_sd = None       # arrives through the RCCL weight broadcast in .to(device)
         if scheduler is None:
             ptype = "v_prediction" if (arch == "sd21" and model_dir is None) else "epsilon"
+            sched_cls = DDIMScheduler          # synthetic pipelines: the scheduler BASELINE.json names
+            sched_kw = {}
             if model_dir is not None and (model_dir / "scheduler" / "scheduler_config.json").exists():
+                # a checkpoint directory decides its own scheduler, as diffusers' from_pretrained does (SD-v1: PNDMScheduler)
+                from .scheduler import SCHEDULERS
                 sc = json.loads((model_dir / "scheduler" / "scheduler_config.json").read_text())
                 ptype = sc.get("prediction_type", "epsilon")
-            scheduler = DDIMScheduler(prediction_type=ptype)
+                sched_cls = SCHEDULERS.get(sc.get("_class_name", "DDIMScheduler"), DDIMScheduler)
+                sched_kw = {k: sc[k] for k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule") if k in sc}
+            scheduler = sched_cls(prediction_type=ptype, **sched_kw)
         text_encoder = build_text_encoder(tcfg, model_dir, seed=synthetic_seed + 2)
         tokenizer = load_tokenizer(model_dir, tcfg)
+        if vae is not None and not isinstance(vae, (_PendingModule, VAEDecoderEngine)):
+            vae = _ForeignVAE(vae)
         pipe = cls(vae=vae or _PendingModule("vae", vcfg, v_sd), text_encoder=text_encoder, tokenizer=tokenizer,
                    unet=_PendingModule("unet", ucfg, u_sd), scheduler=scheduler, safety_checker=safety_checker,
                    feature_extractor=feature_extractor, requires_safety_checker=False, text_config=tcfg)
@@ -275,14 +311,17 @@ class StableDiffusionWalkPipeline:
     # the denoise + decode call
     # ------------------------------------------------------------------------------------------
     def _schedule(self, num_inference_steps: int, eta: float):
-        if not hasattr(self.scheduler, "coefficient_table"):
-            raise NotImplementedError(
-                f"{type(self.scheduler).__name__}: the fused HIP denoise step implements DDIM (epsilon / v-prediction, any "
-                "eta) - the scheduler BASELINE.json names.  The reference also accepts PNDM / LMS / Euler / DPM++ "
-                "(stable_diffusion_pipeline.py:71-78); pass stable_diffusion_videos_amd.DDIMScheduler(...) instead.")
+        """set_timesteps (:394) + the device tables of this schedule.  DDIM (the scheduler BASELINE.json names): {c_x, c_e,
+        sigma} per step for ``sdv_cfg_ddim_step``; every other scheduler of the reference's signature (:71-78): the 16-float
+        rows of ``sdv_cfg_multistep_step`` (scheduler.py).  Returns (key, table, evaluations) - PLMS runs one UNet
+        evaluation more than ``num_inference_steps``."""
+        self.scheduler = adopt_scheduler(self.scheduler)      # (a scheduler assigned after construction)
+        ddim = hasattr(self.scheduler, "coefficient_table")
         self.scheduler.set_timesteps(num_inference_steps)
-        ts = tuple(int(t) for t in self.scheduler.timesteps)
-        key = (ts, float(eta), self.scheduler.config.prediction_type)
+        ts = tuple(float(t) for t in self.scheduler.timesteps)
+        if not ddim:
+            eta = 0.0        # "eta is only used with the DDIMScheduler, it will be ignored for others" (:236, :404-409)
+        key = (type(self.scheduler).__name__, ts, float(eta), self.scheduler.config.prediction_type)
         if key not in self._sched_cache:
             while len(self._sched_cache) >= 8:
                 gone = next(iter(self._sched_cache))
@@ -290,7 +329,7 @@ class StableDiffusionWalkPipeline:
                 # captured steps bake in the pointers of that schedule's coefficient / time-embedding tables
                 for gk in [k for k in self._graphs if k[0] == gone]:
                     self._graphs.pop(gk)["graph"] = None
-            coefs = self.scheduler.coefficient_table(eta).to(self.device)
+            coefs = (self.scheduler.coefficient_table(eta) if ddim else self.scheduler.fused_table()).to(self.device)
             self.unet.prepare_timesteps(ts)
             tables = [r.bias_table for r in self.unet.res]
             self._sched_cache[key] = (coefs, tables)
@@ -314,12 +353,19 @@ class StableDiffusionWalkPipeline:
         self.unet.reserve(nimg, h, w)
         x2 = torch.zeros((nimg * h * w, C), dtype=BF16, device=self.device)
         step = torch.zeros(1, dtype=torch.int32, device=self.device)
-        hip.latents_to_unet_input(lat, x2, cfg, lat.numel())
+        s0 = self.scheduler.first_input_scale() if hasattr(self.scheduler, "first_input_scale") else 1.0
+        hip.latents_to_unet_input(lat if s0 == 1.0 else lat * s0, x2, cfg, lat.numel())
+        multistep = coefs.shape[1] == 16
+        hist = torch.zeros((4,) + tuple(lat.shape), dtype=F32, device=self.device) if multistep else None
+        xsave = torch.zeros_like(lat) if multistep else None
         self.unet.fp8_calibration(True)
         try:
             for _ in range(nsteps):
                 eps = self.unet.forward(x2, nimg, h, w, step, cfg_shared=cfg and self.cfg_shared_prefix)
-                hip.cfg_ddim_step(eps, lat, x2, coefs, step, None, guidance, cfg, lat.numel())
+                if multistep:      # (a stochastic scheduler's noise term is left out of the pilot: it only widens the scales)
+                    hip.cfg_multistep_step(eps, lat, x2, hist, xsave, coefs, step, None, guidance, cfg, lat.numel())
+                else:
+                    hip.cfg_ddim_step(eps, lat, x2, coefs, step, None, guidance, cfg, lat.numel())
                 hip.step_counter_add(step, 1)
         finally:
             self.unet.fp8_calibration(False)
@@ -350,10 +396,18 @@ class StableDiffusionWalkPipeline:
         }
         self.unet.reserve(nimg, h, w)
         n = B * h * w * C
+        multistep = coefs.shape[1] == 16           # sdv_cfg_multistep_step rows (every scheduler but DDIM)
+        if multistep:
+            ent["hist"] = torch.zeros((4, B, h, w, C), dtype=F32, device=dev)      # ring of earlier model outputs
+            ent["xsave"] = torch.zeros((B, h, w, C), dtype=F32, device=dev)        # PLMS: the sample of the first evaluation
 
         def one_step():
             eps = self.unet.forward(ent["x2"], nimg, h, w, ent["step"], cfg_shared=cfg and self.cfg_shared_prefix)
-            hip.cfg_ddim_step(eps, ent["latents"], ent["x2"], coefs, ent["step"], eta_noise, guidance, cfg, n)
+            if multistep:
+                hip.cfg_multistep_step(eps, ent["latents"], ent["x2"], ent["hist"], ent["xsave"], coefs, ent["step"], eta_noise,
+                                       guidance, cfg, n)
+            else:
+                hip.cfg_ddim_step(eps, ent["latents"], ent["x2"], coefs, ent["step"], eta_noise, guidance, cfg, n)
             hip.step_counter_add(ent["step"], 1)
 
         ent["one_step"] = one_step
@@ -439,13 +493,15 @@ class StableDiffusionWalkPipeline:
         latents = latents.to(self.device, F32)
 
         sched_key, coefs, nsteps = self._schedule(num_inference_steps, eta)                       # :394
+        if not hasattr(self.scheduler, "coefficient_table"):
+            eta = 0.0                                                                             # :404-409: DDIM only
         if getattr(self.unet, "fp8", False) and not self.unet.fp8_calibrated:
             self._calibrate_fp8(h, w, coefs, nsteps, float(guidance_scale), do_cfg)
         # A ragged last batch (B frames where a graph for B' > B frames is already captured) is padded with copies of its
         # last frame and replays the big graph: a second capture would own a second multi-GB private pool for one call.
         # Only while the padding is at most a quarter of the big batch - 60 frames replayed as 128 would pay for 128.
         B_real = B
-        if self.use_graphs and eta == 0 and callback is None:
+        if self.use_graphs and eta == 0 and callback is None and not getattr(self.scheduler, "stochastic", False):
             tail = (h, w, do_cfg, float(guidance_scale), False, int(ctx.shape[1]), self.cfg_shared_prefix, self.tiled)
             mult = 2 if do_cfg else 1
             bigger = [k[1] // mult for k in self._graphs if k[0] == sched_key and k[2:] == tail and k[1] // mult > B]
@@ -461,16 +517,17 @@ class StableDiffusionWalkPipeline:
                 B += pad
         nimg = 2 * B if do_cfg else B
         eta_noise = None
-        if eta > 0:
+        stochastic = (eta > 0 and hasattr(self.scheduler, "coefficient_table")) or getattr(self.scheduler, "stochastic", False)
+        if stochastic:
             gdev = generator.device if generator is not None else torch.device("cpu")
             eta_noise = torch.randn((nsteps, B, h, w, C), generator=generator, device=gdev, dtype=F32).to(self.device)
         self.unet.prepare_context(ctx)
         # everything a captured step bakes in: pointers of the (nimg, Lc) cross-attention K/V buffers, the shared-prefix
         # structure, padding mode, guidance scale, schedule
-        gkey = (sched_key, nimg, h, w, do_cfg, float(guidance_scale), eta > 0, int(ctx.shape[1]), self.cfg_shared_prefix,
+        gkey = (sched_key, nimg, h, w, do_cfg, float(guidance_scale), stochastic, int(ctx.shape[1]), self.cfg_shared_prefix,
                 self.tiled)
         ent = self._graph_entry(gkey, nimg, B, h, w, do_cfg, float(guidance_scale), coefs, eta_noise)
-        if eta > 0:
+        if stochastic:
             ent.setdefault("noise", eta_noise)
             if ent["noise"] is not eta_noise:
                 ent["noise"].copy_(eta_noise)
@@ -478,7 +535,9 @@ class StableDiffusionWalkPipeline:
         lat_nhwc = hip.nchw_to_nhwc(latents * self.scheduler.init_noise_sigma)                    # :401
         ent["latents"].copy_(lat_nhwc)
         ent["step"].zero_()
-        hip.latents_to_unet_input(ent["latents"], ent["x2"], do_cfg, ent["latents"].numel())     # :414
+        s0 = self.scheduler.first_input_scale() if hasattr(self.scheduler, "first_input_scale") else 1.0
+        # :414-415: torch.cat([latents] * 2) -> scheduler.scale_model_input (sigma-space schedulers: x / sqrt(sigma_0^2 + 1))
+        hip.latents_to_unet_input(ent["latents"] if s0 == 1.0 else ent["latents"] * s0, ent["x2"], do_cfg, ent["latents"].numel())
         t_prep = time.perf_counter()
         for i in range(nsteps):                                                                   # :412
             if ent["graph"] is not None:
@@ -486,7 +545,7 @@ class StableDiffusionWalkPipeline:
             else:
                 ent["one_step"]()
             if callback is not None and i % callback_steps == 0:                                  # :429
-                callback(i, int(self.scheduler.timesteps[i]), hip.nhwc_to_nchw(ent["latents"]))
+                callback(i, self.scheduler.timesteps[i].item(), hip.nhwc_to_nchw(ent["latents"]))
         if kwargs.get("return_latents", False):
             return hip.nhwc_to_nchw(ent["latents"])[:B_real]
         # "numpy_u8": rounded uint8 NHWC array, no PIL objects; "u8_cuda": the same array left in HBM (upsampler input)

@@ -682,6 +682,42 @@ def test_cfg_ddim_step_matches_oracle(hip, dev):
         assert int(step.item()) == 4
 
 
+@pytest.mark.parametrize("name", ["PNDMScheduler", "LMSDiscreteScheduler", "EulerDiscreteScheduler", "EulerAncestralDiscreteScheduler",
+                                  "DPMSolverMultistepScheduler"])
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction"])
+def test_cfg_multistep_step_matches_oracle(hip, dev, name, ptype):
+    """``sdv_cfg_multistep_step`` (guidance + scheduler.step + the next scale_model_input, one launch) driven by the product's
+    coefficient table, against the oracle's CLASSIC stateful scheduler (stable_diffusion_pipeline.py:415, :422-426 with the
+    schedulers of :71-78) on the same sequence of model outputs - all evaluations of a 12-step schedule, incl. PLMS's repeated
+    second timestep and the history ring wrapping around."""
+    from oracle import scheduler as O
+    from stable_diffusion_videos_amd import scheduler as P
+    o, p = getattr(O, name)(prediction_type=ptype), getattr(P, name)(prediction_type=ptype)
+    o.set_timesteps(12)
+    p.set_timesteps(12)
+    table = p.fused_table().to(dev)
+    n, g = 2 * 8 * 8 * 4, 7.5
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(n, generator=gen) * float(o.init_noise_sigma)
+    lat, ref = x.clone().to(dev), x.clone().double()
+    x2 = torch.empty(2 * n, dtype=BF16, device=dev)
+    hist, xsave = torch.zeros((4, n), device=dev), torch.zeros(n, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    noise = torch.randn((len(o.timesteps), n), generator=gen)
+    for i, t in enumerate(o.timesteps):
+        eps2 = torch.randn(2 * n, generator=gen)
+        e = (eps2[:n] + g * (eps2[n:] - eps2[:n])).double()
+        ref = o.step(e, t, ref, variance_noise=noise[i].double())
+        hip.cfg_multistep_step(eps2.to(dev), lat, x2, hist, xsave, table, step, noise.to(dev) if p.stochastic else None, g, True, n)
+        hip.step_counter_add(step, 1)
+        assert float((lat.cpu().double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (name, ptype, i)
+        if i + 1 < len(o.timesteps):      # the next evaluation's scaled model input, both CFG halves
+            want = o.scale_model_input(lat.cpu(), o.timesteps[i + 1]).to(BF16)
+            assert float((x2[:n].cpu().float() - want.float()).abs().max()) <= 2 ** -7 * float(want.float().abs().max())
+            assert torch.equal(x2[:n], x2[n:])
+    assert int(step.item()) == len(o.timesteps) == (13 if name == "PNDMScheduler" else 12)
+
+
 def test_timestep_embedding_and_linear_small(hip, dev):
     from oracle.models import timestep_embedding
     ts = torch.tensor([981.0, 501.0, 1.0], device=dev)

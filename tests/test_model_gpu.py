@@ -180,6 +180,52 @@ def test_pipeline_call_matches_oracle(hip, dev):
     assert len(ims) == 1 and ims[0].size == (64, 64)
 
 
+@pytest.mark.parametrize("name", ["PNDMScheduler", "LMSDiscreteScheduler", "EulerDiscreteScheduler", "DPMSolverMultistepScheduler",
+                                  "EulerAncestralDiscreteScheduler"])
+def test_pipeline_with_the_other_schedulers(hip, dev, name):
+    """The reference's constructor accepts six schedulers (stable_diffusion_pipeline.py:71-78; SD-v1 checkpoints ship PNDM,
+    examples/make_music_video.py:15 passes LMSDiscrete): __call__ with each of them - hipGraph replay of UNet +
+    ``sdv_cfg_multistep_step`` per evaluation - against the oracle's restated loop (:412-430) with the oracle's classic
+    scheduler of the same name, 8 steps, CFG 7.5.  Same gates as the DDIM test (frame >= 40 dB); graphs == eager bit for bit."""
+    from oracle import scheduler as O
+    from oracle.pipeline import denoise_and_decode
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline
+    from stable_diffusion_videos_amd import scheduler as P
+    pipe = StableDiffusionWalkPipeline.from_pretrained("tiny", scheduler=getattr(P, name)())
+    o_unet, o_vae = _oracle_for((pipe.unet, pipe.vae))
+    pipe.to(dev)
+    emb = pipe.embed_text(["a cat", "a dog"]).cpu()
+    uncond = pipe.embed_text("").cpu()
+    lat = torch.cat([pipe.init_noise(42, (1, 4, 8, 8)), pipe.init_noise(1337, (1, 4, 8, 8))]).cpu()
+    steps = 8
+    osch = getattr(O, name)()
+    osch.set_timesteps(steps)
+    noise = None
+    kw = {}
+    if pipe.scheduler.stochastic:
+        gen = torch.Generator().manual_seed(5)
+        noise = torch.randn((steps, 2, 8, 8, 4), generator=gen)            # [evaluation, B, h, w, C] as the pipeline draws it
+        kw["generator"] = torch.Generator().manual_seed(5)
+    ref = denoise_and_decode(o_unet, o_vae, osch, emb, uncond, lat, num_inference_steps=steps, guidance_scale=7.5,
+                             variance_noise=[z.permute(0, 3, 1, 2) for z in noise] if noise is not None else None)
+    outs = {}
+    for graphs in (True, False):
+        pipe.use_graphs = graphs
+        pipe._graphs.clear()
+        if "generator" in kw:
+            kw["generator"] = torch.Generator().manual_seed(5)
+        outs[graphs] = pipe(latents=lat, text_embeddings=emb, height=64, width=64, num_inference_steps=steps, guidance_scale=7.5,
+                            output_type="numpy", **kw)["images"]
+    p = psnr(torch.from_numpy(outs[True]), torch.from_numpy(ref), peak=1.0)
+    report(f"pipeline with {name}: {len(osch.timesteps)} UNet evaluations, frame PSNR {p:.1f} dB vs the oracle loop")
+    assert outs[True].shape == (2, 64, 64, 3) and p >= 40.0
+    assert np.array_equal(outs[True], outs[False])
+    seen = []
+    pipe(latents=lat[:1], text_embeddings=emb[:1], height=64, width=64, num_inference_steps=steps,
+         callback=lambda i, t, l: seen.append((i, float(t))), **({"generator": torch.Generator().manual_seed(5)} if kw else {}))
+    assert [t for _, t in seen] == [float(t) for t in osch.timesteps]      # callback(i, t, latents) per evaluation, :429-430
+
+
 def test_generate_inputs_matches_reference_semantics(hip, dev):
     """lerp on embeddings, whole-tensor slerp on noise, batches of batch_size with a short last batch
     (stable_diffusion_pipeline.py:464-479), against the oracle restatement."""
