@@ -112,6 +112,11 @@ typedef struct sdv_gemm_args {
     int32_t out_mode;
     float* out_f32;
     uint8_t* out_u8;
+    /* conv modes, K-loop order of the 8-wave double-buffered tiles: 0 = tap-major (for each of the 9 taps: all channel slabs),
+     * 1 = channel-major (for each 64-channel slab: all taps).  Same products, a different summation order; channel-major
+     * re-reads a pixel's 128 bytes nine slabs in a row, so the 32 workgroups of an XCD keep their shifted windows inside the
+     * 4 MiB L2 instead of re-fetching every tap from the fabric (profiles/round3_*).  -1 = the library's default. */
+    int32_t k_order;
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     int kx = 0;   // scalar byte offset inside the current X source
     int kwb = 0;  // scalar byte offset along the W rows (all taps and sources are contiguous in K)
 
+    // channel-major K order (sdv_hip.h k_order 1) - an EXPERIMENT kept selectable: it cuts the conv's fabric reads 3.2x and is
+    // 5-12 % slower (profiles/round3_conv_k_order.txt), so the default stays tap-major
+    const bool chan_major = CONV && p.k_order == 1 && p.mode != 0;
     auto setup_tile = [&](int vb) {
         const int bz = vb / nblk;           // batch index (mode 4: the phase)
         const int lb = vb - bz * nblk;
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 xr_[i] = m < p.M ? img * p.Hin * p.Win - pix0 : -1;
                 xay[i] = oy * st;
                 xax[i] = ox * st;
+
             } else {
                 xr_[i] = m < p.M ? r : -1;
                 xay[i] = 0;
@@ -236,9 +240,51 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         seg_left = (srcsel ? K - p.C1 : p.C1) / BK;
     };
 
+    // Channel-major K order (sdv_hip.h k_order 1, conv modes): for each 64-channel slab ALL taps, so that a pixel's 128 bytes are
+    // re-read nine slabs in a row (from L2) instead of once per tap pass with the whole window in between.  The per-lane tap
+    // offsets are recomputed every slab (new_segment's ~10 VALU per X piece, hidden under the slab's 40 MFMAs); W columns are
+    // [tap][source][channel], so the slab's W offset is tap * K + (source 2 ? C1 : 0) + channel.
+    const int ntaps_k = CONV ? (p.mode == 4 ? 4 : 9) : 1;
     // `issue` false: only the bookkeeping of a slab that is already in LDS (the prefetched first slab of a persistent tile)
     auto stage = [&](int buf, bool issue = true) {
         char* base = smem + buf * SLOT;
+        if constexpr (CONV) {
+            if (chan_major) {
+                if (issue) {
+                    const int x_soff = kx;
+                    {
+                        const int kx_keep = kx;
+                        new_segment();             // xvo for (tap, srcsel); it also resets kx / seg_left, which this order does not use
+                        kx = kx_keep;
+                    }
+                    const __amdgpu_buffer_rsrc_t rs_xc = srcsel ? rs_x2 : rs_x1;
+                    const int kw_off = (tap * K + (srcsel ? p.C1 : 0)) * ES + kx;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        const int g = wave + NWV * i;
+                        if (GX % NWV == 0 || g < GX)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xc, (__attribute__((address_space(3))) void*)(base + g * 1024), 16,
+                                                                     (int)xvo[i], x_soff, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) {
+                        const int g = wave + NWV * i;
+                        if (GW % NWV == 0 || g < GW)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024),
+                                                                     16, (int)wvo[i], kw_off, 0, 0);
+                    }
+                }
+                if (++tap == ntaps_k) {            // next channel slab (of this source, then of the second one)
+                    tap = 0;
+                    kx += ROWB;
+                    if (kx == (srcsel ? K - p.C1 : p.C1) * ES) {
+                        kx = 0;
+                        srcsel = (two_src && srcsel == 0) ? 1 : 0;
+                    }
+                }
+                return;
+            }
+        }
         if (seg_left == 0) new_segment();
         const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
         if (issue) {
@@ -1129,6 +1175,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     }
 }
 
+constexpr int kDefaultConvKOrder = 0;   // sdv_gemm_args.k_order -1 resolves to this (tap-major; see profiles/round3_conv_k_order.txt)
 int g_persistent = 1;   // sdv_gemm_set_persistent(): A/B switch for tools/ (0 = one workgroup per tile, as in round 1)
 
 int current_device() {
@@ -1233,6 +1280,8 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         SDV_REQUIRE(a.tile == 0 || (a.tile >= 1 && a.tile <= 4) || a.tile == 10 || a.tile == 11, "sdv_gemm_bf16: out_mode exists in the 4-wave tiles only");
         if (a.tile == 0) a.tile = 10;   // 256 x 32: one 32-column MFMA tile holds all the outputs
     }
+    SDV_REQUIRE(a.k_order >= -1 && a.k_order <= 1, "sdv_gemm_bf16: bad k_order %d", a.k_order);
+    if (a.k_order < 0) a.k_order = kDefaultConvKOrder;
     SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SDV_REQUIRE(a.K % 64 == 0, "sdv_gemm_bf16: K=%d must be a multiple of 64", a.K);
     SDV_REQUIRE(a.mode >= 0 && a.mode <= 4, "sdv_gemm_bf16: bad mode %d", a.mode);

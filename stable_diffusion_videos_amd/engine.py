@@ -554,6 +554,7 @@ class VAEDecoderEngine:
         self.conv_out_w, self.conv_out_b = conv_w(sd["decoder.conv_out.weight"], dev), vec(sd["decoder.conv_out.bias"], dev)
         self.groups = g
         self.scale_factor = 2 ** (len(cfg.block_out_channels) - 1)
+        self.score_chunk_bytes = 512 << 20      # mid-block attention: bytes of [HW, HW] bf16 scores materialised at a time
 
     def _attention(self, x, nimg, H, W):
         out = self._attention_impl(x, nimg, H, W)
@@ -567,12 +568,18 @@ class VAEDecoderEngine:
         vt = torch.empty((nimg, C, HW), dtype=BF16, device=x.device)
         hip.gemm(self.a_wv, n, vt, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=HW, bias=self.a_bv, bias_mode=2, batch=nimg,
                  sX=0, sW=HW * C, sC=C * HW)                                         # V^T (+ bias per channel)
-        s = torch.empty((nimg, HW, HW), dtype=BF16, device=x.device)
-        hip.gemm(qk, qk, s, M=HW, N=HW, K=C, ldx=2 * C, ldw=2 * C, ldc=HW, alpha=C ** -0.5, batch=nimg,
-                 sX=HW * 2 * C, sW=HW * 2 * C, sC=HW * HW, w_off=C)                  # S = Q K^T / sqrt(C)
-        hip.softmax_rows_(s, nimg * HW, HW, HW)
         o = torch.empty((nimg * HW, C), dtype=BF16, device=x.device)
-        hip.gemm(s, vt, o, M=HW, N=C, K=HW, ldx=HW, ldw=HW, ldc=C, batch=nimg, sX=HW * HW, sW=C * HW, sC=HW * C)
+        # The one place a score matrix is materialised (1 head x 512 channels: the flash kernel has no dh = 512 instance): in
+        # chunks of images whose [HW, HW] bf16 scores stay under 512 MiB - 128 frames used to allocate 4.3 GB in one piece
+        per = max(1, self.score_chunk_bytes // (2 * HW * HW))
+        s = torch.empty((min(per, nimg), HW, HW), dtype=BF16, device=x.device)
+        for i0 in range(0, nimg, per):
+            nb = min(per, nimg - i0)
+            hip.gemm(qk, qk, s, M=HW, N=HW, K=C, ldx=2 * C, ldw=2 * C, ldc=HW, alpha=C ** -0.5, batch=nb,
+                     sX=HW * 2 * C, sW=HW * 2 * C, sC=HW * HW, x_off=i0 * HW * 2 * C, w_off=i0 * HW * 2 * C + C)   # S = Q K^T / sqrt(C)
+            hip.softmax_rows_(s, nb * HW, HW, HW)
+            hip.gemm(s, vt, o, M=HW, N=C, K=HW, ldx=HW, ldw=HW, ldc=C, batch=nb, sX=HW * HW, sW=C * HW, sC=HW * C,
+                     w_off=i0 * C * HW, out_off=i0 * HW * C)
         return hip.linear(o, self.a_wo, self.a_bo, residual=x)
 
     def decode(self, latents: torch.Tensor, want_float: bool = False):

@@ -38,10 +38,11 @@ class GemmArgs(C.Structure):
         ("alpha_cols", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
         ("fp8", C.c_int32), ("out_mode", C.c_int32), ("out_f32", C.c_void_p), ("out_u8", C.c_void_p),
+        ("k_order", C.c_int32),
     ]
 
 
-ABI_VERSION = 6     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 7     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -139,6 +140,7 @@ FP8 = torch.float8_e4m3fn      # OCP e4m3, what gfx950's fp8 MFMA and converters
 FP8_MAX = 448.0
 
 _zero_pages = {}
+K_ORDER = int(os.environ.get("SDV_CONV_K_ORDER", "-1"))    # developer knob for A/B (tools/conv_order_ab.py); -1 = library default
 
 # Optional launch observer used by bench.py's roofline pass: called as hook(kind, info_dict, launch_fn).  The
 # hook must call launch_fn() itself (it may bracket it with HIP events).  None = no overhead.
@@ -170,7 +172,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
          x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None, ln_side: int = 1,
          want_stats: bool = False, ln_eps: float = 1e-5, out_mode: int = 0, out_f32: Optional[torch.Tensor] = None,
-         out_u8: Optional[torch.Tensor] = None):
+         out_u8: Optional[torch.Tensor] = None, k_order: int = -1):
     """Raw wrapper of ``sdv_gemm_bf16`` (element offsets x_off / w_off / out_off select sub-matrices).
     ``out_mode`` 1 / 2: fp32 output / image epilogue into ``out_f32`` / ``out_u8`` (``out`` may be None), see sdv_hip.h.
     ``ln=(stats, s)``: LayerNorm folded into this GEMM (sdv_hip.h): ``stats`` fp32 [rows, 2] = (mean, rstd) from
@@ -192,6 +194,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     a.R = _ptr(residual, BF16, "R")
     a.C = _ptr(out, BF16, "C") + 2 * out_off if out is not None else None
     a.out_mode, a.out_f32, a.out_u8 = out_mode, _ptr(out_f32, F32, "out_f32"), _ptr(out_u8, torch.uint8, "out_u8")
+    a.k_order = K_ORDER if k_order < 0 else k_order
     a.step_ptr = _ptr(step_ptr, torch.int32, "step_ptr")
     a.zero_page = zero_page(x.device).data_ptr()
     a.sX, a.sW, a.sC, a.sR = sX, sW, sC, sR

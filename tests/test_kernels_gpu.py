@@ -271,6 +271,28 @@ def test_conv3x3_is_correctly_rounded(hip, dev, tile, mode):
     assert float(ratio.max()) <= 1.0, f"tile {tile} mode {mode}: {float(ratio.max()):.3f} x the rounding + accumulation bound"
 
 
+@pytest.mark.parametrize("mode,circular", [(1, False), (1, True), (2, False), (3, False)])
+def test_conv3x3_channel_major_k_order(hip, dev, mode, circular):
+    """sdv_hip.h ``k_order`` 1 (for each 64-channel slab all nine taps - the experiment of profiles/round3_conv_k_order.txt):
+    the same convolution as the default tap-major order up to the fp32 summation order, two-source concat included, on a
+    shape large enough for the persistent 256 x 320 tile."""
+    from stable_diffusion_videos_amd.weights import conv_w
+    n, H, W, C1, C2, Cout = 6, 32, 32, 128, 64, 320
+    x, x2 = rnd((n, H, W, C1), dev, 70), rnd((n, H, W, C2), dev, 71)
+    w, bias = rnd((Cout, C1 + C2, 3, 3), dev, 72, (9 * (C1 + C2)) ** -0.5), rnd((Cout,), dev, 73)
+    ref = conv_ref(torch.cat([x, x2], -1), w, bias, mode, circular)
+    M, Ho = ref.numel() // Cout, ref.shape[1]
+    outs = []
+    for order in (0, 1):
+        out = torch.empty((M, Cout), dtype=BF16, device=dev)
+        hip.gemm(x.reshape(-1, C1).to(BF16), conv_w(w, dev), out, M=M, N=Cout, K=C1 + C2, ldx=C1, ldw=9 * (C1 + C2), ldc=Cout,
+                 bias=bias, x2=x2.reshape(-1, C2).to(BF16), C1=C1, ldx2=C2, mode=mode, Hin=H, Win=W, Hout=Ho, Wout=ref.shape[2],
+                 circular=circular, tile=6, k_order=order)
+        assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL, order
+        outs.append(out)
+    assert rel_l2(outs[1].float(), outs[0].float()) < 1e-3
+
+
 @pytest.mark.parametrize("tile", [0, 1, 6, 9, 12])
 @pytest.mark.parametrize("circular", [False, True])
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320), (1, 6, 10, 64, 40)])

@@ -1,0 +1,17 @@
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3e; mkdir -p $O
+cd $R
+python -m pytest tests/test_model_gpu.py tests/test_video.py tests/test_audio.py -x -q -m gpu -k "other_schedulers or vae_attention_score or generate_inputs or walk or call_argument or sd14_full or config1 or sd21 or variants or cfg_shared or two_rank or rccl or bench_launches or ragged or esrgan or clip or generate_images" > $O/model_rest.log 2>&1; echo "rc=$?" >> $O/model_rest.log; tail -6 $O/model_rest.log
+export TMPDIR=/tmp
+cd /tmp
+SDV_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-walk-pass > $O/kt_bench.json 2> $O/kt.err; echo "kt rc=$?"
+timeout 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/p1 -- python $R/tools/unet_once.py 128 > $O/p1.log 2>&1; echo "p1 rc=$?"
+timeout 400 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -- python $R/tools/unet_once.py 128 > $O/p2.log 2>&1; echo "p2 rc=$?"
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/p3 -- python $R/tools/unet_once.py 128 > $O/p3.log 2>&1; echo "p3 rc=$?"
+cd $R
+python tools/pmc_summary.py $O/round3_pmc_unet_b128.csv $(find $O/p1 $O/p2 $O/p3 -name "*counter_collection.csv") | tail -2
+find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/round3_bench_b128_kernel_stats.csv \;
+head -5 $O/round3_bench_b128_kernel_stats.csv
+# keep the merge small: drop the raw traces
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
+du -sh $O
