@@ -131,3 +131,21 @@ def test_mjpeg_mp4_carries_the_audio_window(tmp_path):
     lo, hi = find_in(buf, va, vb, stbl + ("stco",))
     v_off = struct.unpack(">III", buf[lo:lo + 12])[2]
     assert buf[v_off:v_off + 2] == b"\xff\xd8"
+
+
+def test_h264_aac_path_when_pyav_is_present(tmp_path):
+    """The reference's encoding (utils.py:69-128: ``torchvision.io.write_video(..., options={"crf": "10", "pix_fmt": "yuv420p"},
+    audio_codec="aac")``) is taken whenever torchvision + pyav are importable; neither is in this image, so this test skips
+    here and runs wherever they exist: the file must then carry an H.264 video track (sample entry ``avc1``) instead of the
+    Motion-JPEG fallback's ``mp4v``."""
+    pytest.importorskip("av")
+    pytest.importorskip("torchvision")
+    from PIL import Image
+    d = tmp_path / "frames"
+    d.mkdir()
+    rng = np.random.RandomState(0)
+    for k in range(6):
+        Image.fromarray(rng.randint(0, 255, (64, 64, 3), dtype=np.uint8)).save(d / f"frame{k:06d}.png")
+    out = make_video_pyav(d, fps=6, output_filepath=tmp_path / "h264.mp4", glob_pattern="*.png")
+    data = open(out, "rb").read()
+    assert b"avc1" in data and b"mp4v" not in data
