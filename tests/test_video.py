@@ -4,6 +4,7 @@ import io
 import struct
 
 import numpy as np
+import pytest
 import torch
 from PIL import Image
 
