@@ -6,8 +6,9 @@
                             (stable_diffusion_pipeline.py:432-438, numpy_to_pil :450)
 
 Everything is NHWC / token-major bf16 in HBM ([N*H*W, C] row-major), so the UNet's conv <-> transformer
-boundaries need no permutes.  Each method only enqueues HIP kernels (through ``hip``, the ctypes binding of
-libsdv_hip.so) on the current stream: a whole denoise step is therefore capturable in one hipGraph.
+boundaries need no permutes.  Each method only enqueues HIP kernels - through the wrappers of ``hip``, each of which
+dispatches one ``torch.ops.sdv.k_*`` custom op onto the C ABI of libsdv_hip.so - on the current stream: a whole denoise
+step is therefore capturable in one hipGraph.
 
 What is hoisted out of the 50-step loop (the reference recomputes all of it every step):
   * the timestep-embedding MLP and the 22 ``time_emb_proj`` projections: the walk uses the same timestep

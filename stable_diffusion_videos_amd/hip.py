@@ -154,6 +154,30 @@ def _launch(kind: str, info: dict, fn):
         LAUNCH_HOOK(kind, info, fn)
 
 
+# ------------------------------------------------------------------------------------------------
+# torch.ops.sdv.k_* : every launch on the hot path is a PyTorch custom op
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's north_star: "Python host code calling hand-written CDNA4 HIP kernels through PyTorch-ROCm custom ops".  The public
+# wrappers below (gemm / linear / conv3x3 / attention / groupnorm / cfg_*_step / lerp / slerp ...) - which is what engine.py and
+# pipeline.py call - do not touch ctypes themselves: they pack their arguments and call ``torch.ops.sdv.k_<name>``, a dispatcher
+# op registered here with a schema (mutated outputs annotated), an implementation that hands ``data_ptr()`` + the current HIP
+# stream to the C ABI, and a Meta (fake) kernel.  Registered through ``torch.library.Library`` rather than
+# ``torch.library.custom_op``: 6 us per call instead of 31 us (measured), which matters for the ~400 launches of an eager UNet
+# forward and not at all once a step is a hipGraph replay.  There is still no CPU kernel: the one implementation raises
+# ``SdvHipError`` for a tensor that is not in GPU memory.
+_OPLIB = torch.library.Library("sdv", "FRAGMENT")
+KERNEL_OPS = []
+
+
+def _defop(schema: str, impl, fake=None):
+    name = schema[:schema.index("(")]
+    _OPLIB.define(schema)
+    _OPLIB.impl(name, impl, "CompositeExplicitAutograd")
+    _OPLIB.impl(name, fake if fake is not None else (lambda *a, **k: None), "Meta")
+    KERNEL_OPS.append(name)
+    return getattr(torch.ops.sdv, name)
+
+
 def zero_page(device) -> torch.Tensor:
     key = str(device)
     if key not in _zero_pages:
@@ -164,47 +188,42 @@ def zero_page(device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # GEMM / conv
 # ------------------------------------------------------------------------------------------------
-def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, ldx: int, ldw: int,
-         ldc: int, bias: Optional[torch.Tensor] = None, bias_mode: int = 1, residual: Optional[torch.Tensor] = None,
-         ldr: int = 0, x2: Optional[torch.Tensor] = None, C1: int = 0, ldx2: int = 0, alpha: float = 1.0,
-         epi: int = 0, mode: int = 0, Hin: int = 0, Win: int = 0, Hout: int = 0, Wout: int = 0,
-         circular: bool = False, batch: int = 1, sX: int = 0, sW: int = 0, sC: int = 0, sR: int = 0,
-         step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
-         x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None, ln_side: int = 1,
-         want_stats: bool = False, ln_eps: float = 1e-5, out_mode: int = 0, out_f32: Optional[torch.Tensor] = None,
-         out_u8: Optional[torch.Tensor] = None, k_order: int = -1):
-    """Raw wrapper of ``sdv_gemm_bf16`` (element offsets x_off / w_off / out_off select sub-matrices).
-    ``out_mode`` 1 / 2: fp32 output / image epilogue into ``out_f32`` / ``out_u8`` (``out`` may be None), see sdv_hip.h.
-    ``ln=(stats, s)``: LayerNorm folded into this GEMM (sdv_hip.h): ``stats`` fp32 [rows, 2] = (mean, rstd) from
-    ``want_stats`` of the producer, ``s`` fp32 row sums of the gamma-scaled weights.  ``want_stats=True`` returns the
-    (mean, rstd) [batch*M, 2] of this GEMM's OUTPUT rows over its N columns (for the next LayerNorm)."""
+_GEMM_INTS = ("M", "N", "K", "ldx", "ldw", "ldc", "ldr", "C1", "ldx2", "epi", "mode", "Hin", "Win", "Hout", "Wout", "circular", "batch",
+              "sX", "sW", "sC", "sR", "bias_mode", "bias_step_stride", "tile", "x_off", "w_off", "out_off", "alpha_cols", "ln_side",
+              "out_mode", "k_order")
+
+
+def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32, out_u8, ints, alpha, ln_eps, want_stats):
+    """sdv::k_igemm - the launch of ``sdv_gemm_bf16`` (+ ``sdv_rowstats_finalize`` when the row statistics are wanted)."""
+    g = dict(zip(_GEMM_INTS, ints))
+    M, N, K, batch, mode, epi = g["M"], g["N"], g["K"], g["batch"], g["mode"], g["epi"]
     lib = load()
     a = GemmArgs()
     fp8 = x.dtype == FP8
     if fp8:
-        if w.dtype != FP8 or (x2 is not None and x2.dtype != FP8) or x_off or w_off:
+        if w.dtype != FP8 or (x2 is not None and x2.dtype != FP8) or g["x_off"] or g["w_off"]:
             raise SdvHipError("gemm: fp8 activations need fp8 weights (and no operand offsets)")
         a.fp8 = 1
         a.X, a.X2, a.W = _ptr(x, FP8, "X"), _ptr(x2, FP8, "X2"), _ptr(w, FP8, "W")
     else:
-        a.X = _ptr(x, BF16, "X") + 2 * x_off
+        a.X = _ptr(x, BF16, "X") + 2 * g["x_off"]
         a.X2 = _ptr(x2, BF16, "X2")
-        a.W = _ptr(w, BF16, "W") + 2 * w_off
+        a.W = _ptr(w, BF16, "W") + 2 * g["w_off"]
     a.bias = _ptr(bias, F32, "bias")
     a.R = _ptr(residual, BF16, "R")
-    a.C = _ptr(out, BF16, "C") + 2 * out_off if out is not None else None
-    a.out_mode, a.out_f32, a.out_u8 = out_mode, _ptr(out_f32, F32, "out_f32"), _ptr(out_u8, torch.uint8, "out_u8")
-    a.k_order = K_ORDER if k_order < 0 else k_order
+    a.C = _ptr(out, BF16, "C") + 2 * g["out_off"] if out is not None else None
+    a.out_mode, a.out_f32, a.out_u8 = g["out_mode"], _ptr(out_f32, F32, "out_f32"), _ptr(out_u8, torch.uint8, "out_u8")
+    a.k_order = K_ORDER if g["k_order"] < 0 else g["k_order"]
     a.step_ptr = _ptr(step_ptr, torch.int32, "step_ptr")
     a.zero_page = zero_page(x.device).data_ptr()
-    a.sX, a.sW, a.sC, a.sR = sX, sW, sC, sR
+    a.sX, a.sW, a.sC, a.sR = g["sX"], g["sW"], g["sC"], g["sR"]
     a.M, a.N, a.K = M, N, K
-    a.ldx, a.ldx2, a.C1, a.ldw, a.ldc, a.ldr = ldx, ldx2, C1, ldw, ldc, ldr
-    a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, Hin, Win, Hout, Wout, int(circular)
-    a.epi, a.bias_mode, a.bias_step_stride = epi, (bias_mode if bias is not None else 0), bias_step_stride
-    a.batch, a.tile, a.alpha, a.alpha_cols = batch, tile, alpha, alpha_cols
-    if ln is not None:
-        a.ln_stats, a.ln_s, a.ln_side = _ptr(ln[0], F32, "ln_stats"), _ptr(ln[1], F32, "ln_s"), ln_side
+    a.ldx, a.ldx2, a.C1, a.ldw, a.ldc, a.ldr = g["ldx"], g["ldx2"], g["C1"], g["ldw"], g["ldc"], g["ldr"]
+    a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, g["Hin"], g["Win"], g["Hout"], g["Wout"], g["circular"]
+    a.epi, a.bias_mode, a.bias_step_stride = epi, (g["bias_mode"] if bias is not None else 0), g["bias_step_stride"]
+    a.batch, a.tile, a.alpha, a.alpha_cols = batch, g["tile"], alpha, g["alpha_cols"]
+    if ln_stats is not None:
+        a.ln_stats, a.ln_s, a.ln_side = _ptr(ln_stats, F32, "ln_stats"), _ptr(ln_s, F32, "ln_s"), g["ln_side"]
     partials = None
     if want_stats:
         a.stats_out = 16          # (non-null while planning: the tile choice depends on it)
@@ -227,7 +246,38 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
                 lambda: _check(lib.sdv_rowstats_finalize(partials.data_ptr(), partials.shape[0], partials.shape[1], nout, ln_eps,
                                                          stats.data_ptr(), _stream()), "sdv_rowstats_finalize"))
         return stats
-    return None
+    return torch.empty(0, dtype=F32, device=x.device)
+
+
+def _igemm_fake(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32, out_u8, ints, alpha, ln_eps, want_stats):
+    g = dict(zip(_GEMM_INTS, ints))
+    return x.new_empty((max(g["batch"], 1) * g["M"], 2) if want_stats else (0,), dtype=F32)
+
+
+_k_igemm = _defop("k_igemm(Tensor x, Tensor w, Tensor(a!)? out, Tensor? bias, Tensor? residual, Tensor? x2, Tensor? ln_stats, "
+                  "Tensor? ln_s, Tensor? step_ptr, Tensor(b!)? out_f32, Tensor(c!)? out_u8, int[] ints, float alpha, float ln_eps, "
+                  "bool want_stats) -> Tensor", _igemm_impl, _igemm_fake)
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, ldx: int, ldw: int,
+         ldc: int, bias: Optional[torch.Tensor] = None, bias_mode: int = 1, residual: Optional[torch.Tensor] = None,
+         ldr: int = 0, x2: Optional[torch.Tensor] = None, C1: int = 0, ldx2: int = 0, alpha: float = 1.0,
+         epi: int = 0, mode: int = 0, Hin: int = 0, Win: int = 0, Hout: int = 0, Wout: int = 0,
+         circular: bool = False, batch: int = 1, sX: int = 0, sW: int = 0, sC: int = 0, sR: int = 0,
+         step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
+         x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None, ln_side: int = 1,
+         want_stats: bool = False, ln_eps: float = 1e-5, out_mode: int = 0, out_f32: Optional[torch.Tensor] = None,
+         out_u8: Optional[torch.Tensor] = None, k_order: int = -1):
+    """``sdv_gemm_bf16`` through ``torch.ops.sdv.k_igemm`` (element offsets x_off / w_off / out_off select sub-matrices).
+    ``out_mode`` 1 / 2: fp32 output / image epilogue into ``out_f32`` / ``out_u8`` (``out`` may be None), see sdv_hip.h.
+    ``ln=(stats, s)``: LayerNorm folded into this GEMM (sdv_hip.h): ``stats`` fp32 [rows, 2] = (mean, rstd) from
+    ``want_stats`` of the producer, ``s`` fp32 row sums of the gamma-scaled weights.  ``want_stats=True`` returns the
+    (mean, rstd) [batch*M, 2] of this GEMM's OUTPUT rows over its N columns (for the next LayerNorm)."""
+    ints = [M, N, K, ldx, ldw, ldc, ldr, C1, ldx2, epi, mode, Hin, Win, Hout, Wout, int(circular), batch, sX, sW, sC, sR, bias_mode,
+            bias_step_stride, tile, x_off, w_off, out_off, alpha_cols, ln_side, out_mode, k_order]
+    st = _k_igemm(x, w, out, bias, residual, x2, ln[0] if ln is not None else None, ln[1] if ln is not None else None, step_ptr,
+                  out_f32, out_u8, ints, float(alpha), float(ln_eps), bool(want_stats))
+    return st if want_stats else None
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, residual=None, out=None,
@@ -307,11 +357,8 @@ def upconv3x3_phase(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tens
 # ------------------------------------------------------------------------------------------------
 # attention / norms
 # ------------------------------------------------------------------------------------------------
-def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Lq: int,
-              Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0,
-              causal: bool = False, q_prescaled: bool = False):
-    """softmax(Q K^T scale) V.  ``q_prescaled``: Q already holds q * scale * log2(e) (``LOG2E_SCALE(dh)`` applied as the
-    ``alpha`` of its projection GEMM, one bf16 rounding in total) and ``scale`` is ignored."""
+def _attention_impl(q, k, vt, out, ints, scale, causal, q_prescaled):
+    B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off = ints
     lib = load()
     qp, kp, vp, op = _ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off, _ptr(vt, BF16, "Vt"), _ptr(out, BF16, "O")
     _launch("attention", dict(B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, flops=4.0 * B * H * Lq * Lk * dh),
@@ -320,14 +367,33 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
                            "sdv_attention_bf16"))
 
 
+_k_attention = _defop("k_attention(Tensor q, Tensor k, Tensor vt, Tensor(a!) out, int[] ints, float scale, bool causal, "
+                      "bool q_prescaled) -> ()", _attention_impl)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Lq: int,
+              Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0,
+              causal: bool = False, q_prescaled: bool = False):
+    """softmax(Q K^T scale) V (``torch.ops.sdv.k_attention``).  ``q_prescaled``: Q already holds q * scale * log2(e)
+    (``LOG2E_SCALE(dh)`` applied as the ``alpha`` of its projection GEMM, one bf16 rounding in total) and ``scale`` is ignored."""
+    _k_attention(q, k, vt, out, [B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off], float(scale), bool(causal), bool(q_prescaled))
+
+
 def q_prescale(dh: int) -> float:
     """softmax scale * log2(e): what the attention kernels want Q multiplied by (they exponentiate in base 2)."""
     return dh ** -0.5 * 1.4426950408889634
 
 
-def softmax_rows_(s: torch.Tensor, rows: int, cols: int, ld: int):
+def _softmax_rows_impl(s, rows, cols, ld):
     lib = load()
     _check(lib.sdv_softmax_rows_bf16(_ptr(s, BF16, "S"), rows, cols, ld, _stream()), "sdv_softmax_rows_bf16")
+
+
+_k_softmax_rows = _defop("k_softmax_rows_(Tensor(a!) s, int rows, int cols, int ld) -> ()", _softmax_rows_impl)
+
+
+def softmax_rows_(s: torch.Tensor, rows: int, cols: int, ld: int):
+    _k_softmax_rows(s, rows, cols, ld)
 
 
 def gn_splits(HW: int) -> int:
@@ -338,99 +404,146 @@ def gn_splits(HW: int) -> int:
     return max(1, min(64, HW // pix))
 
 
-def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg: int, HW: int, groups: int,
-              eps: float, silu: bool, x2: Optional[torch.Tensor] = None, out=None, fp8_scale: Optional[float] = None) -> torch.Tensor:
-    """GroupNorm(+SiLU) over NHWC [nimg*HW, C1] (++ [.., C2] concatenated on channels) -> bf16 [.., C1+C2].
-    ``fp8_scale`` s: the result is written as OCP e4m3 bytes q = sat(y / s) instead (y ~ q * s), the fp8 conv's operand."""
+def _groupnorm_impl(x, gamma, beta, x2, out, ints, eps, fp8_scale):
+    nimg, HW, groups, silu = ints
     lib = load()
     C1 = x.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     splits = gn_splits(HW)
     partials = torch.empty((nimg, splits, groups, 2), dtype=F32, device=x.device)
-    if out is None:
-        out = torch.empty((nimg * HW, C1 + C2), dtype=BF16 if fp8_scale is None else FP8, device=x.device)
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise SdvHipError("groupnorm: inputs must be contiguous")
+    fp8 = fp8_scale > 0.0
     nbytes = 2.0 * nimg * HW * (C1 + C2)
-    xp, x2p, pp, op = _ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), _ptr(partials), _ptr(out, BF16 if fp8_scale is None else FP8, "Y")
+    xp, x2p, pp, op = _ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), _ptr(partials), _ptr(out, FP8 if fp8 else BF16, "Y")
     gp, bp = _ptr(gamma, F32, "gamma"), _ptr(beta, F32, "beta")
     _launch("gn_stats", dict(bytes=nbytes),
             lambda: _check(lib.sdv_groupnorm_stats(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, _stream()),
                            "sdv_groupnorm_stats"))
-    if fp8_scale is not None:
+    if fp8:
         _launch("gn_apply", dict(bytes=1.5 * nbytes),
                 lambda: _check(lib.sdv_groupnorm_apply_fp8(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, gp, bp, eps, int(silu),
                                                            op, 1.0 / fp8_scale, _stream()), "sdv_groupnorm_apply_fp8"))
-        return out
+        return
     _launch("gn_apply", dict(bytes=2 * nbytes),
             lambda: _check(lib.sdv_groupnorm_apply(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, gp, bp, eps, int(silu),
                                                    op, _stream()), "sdv_groupnorm_apply"))
+
+
+_k_groupnorm = _defop("k_groupnorm(Tensor x, Tensor gamma, Tensor beta, Tensor? x2, Tensor(a!) out, int[] ints, float eps, "
+                      "float fp8_scale) -> ()", _groupnorm_impl)
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg: int, HW: int, groups: int,
+              eps: float, silu: bool, x2: Optional[torch.Tensor] = None, out=None, fp8_scale: Optional[float] = None) -> torch.Tensor:
+    """GroupNorm(+SiLU) over NHWC [nimg*HW, C1] (++ [.., C2] concatenated on channels) -> bf16 [.., C1+C2]
+    (``torch.ops.sdv.k_groupnorm``: statistics pass + apply pass).
+    ``fp8_scale`` s: the result is written as OCP e4m3 bytes q = sat(y / s) instead (y ~ q * s), the fp8 conv's operand."""
+    C1 = x.shape[1]
+    C2 = x2.shape[1] if x2 is not None else 0
+    if out is None:
+        out = torch.empty((nimg * HW, C1 + C2), dtype=BF16 if fp8_scale is None else FP8, device=x.device)
+    _k_groupnorm(x, gamma, beta, x2, out, [nimg, HW, groups, int(silu)], float(eps), float(fp8_scale) if fp8_scale is not None else 0.0)
     return out
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None) -> torch.Tensor:
+def _layernorm_impl(x, gamma, beta, eps, out):
     lib = load()
     rows, Cn = x.shape
     if not x.is_contiguous():
         raise SdvHipError("layernorm: input must be contiguous")
-    if out is None:
-        out = torch.empty_like(x)
     xp, gp, bp, op = _ptr(x, BF16, "X"), _ptr(gamma, F32), _ptr(beta, F32), _ptr(out, BF16)
     _launch("layernorm", dict(bytes=4.0 * rows * Cn),
             lambda: _check(lib.sdv_layernorm_bf16(xp, gp, bp, eps, rows, Cn, op, _stream()), "sdv_layernorm_bf16"))
+
+
+_k_layernorm = _defop("k_layernorm(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor(a!) out) -> ()", _layernorm_impl)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out=None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    _k_layernorm(x, gamma, beta, float(eps), out)
     return out
 
 
 # ------------------------------------------------------------------------------------------------
 # small convs / latents
 # ------------------------------------------------------------------------------------------------
-def conv3x3_cin_small(x, w, bias, *, nimg, H, W, circular=False, out=None):
+def _conv3x3_cin_small_impl(x, w, bias, out, nimg, H, W, circular):
     lib = load()
-    Cin = x.shape[1]
-    Cout = w.shape[0]
-    if out is None:
-        out = torch.empty((nimg * H * W, Cout), dtype=BF16, device=x.device)
+    Cin, Cout = x.shape[1], w.shape[0]
     xp, wp, bp, op = _ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out, BF16)
     _launch("conv_cin_small", dict(flops=18.0 * nimg * H * W * Cin * Cout, bytes=2.0 * nimg * H * W * (Cin + Cout)),
             lambda: _check(lib.sdv_conv3x3_cin_small(xp, wp, bp, op, nimg, H, W, Cin, Cout, int(circular), _stream()),
                            "sdv_conv3x3_cin_small"))
+
+
+_k_conv3x3_cin_small = _defop("k_conv3x3_cin_small(Tensor x, Tensor w, Tensor? bias, Tensor(a!) out, int nimg, int H, int W, "
+                              "bool circular) -> ()", _conv3x3_cin_small_impl)
+
+
+def conv3x3_cin_small(x, w, bias, *, nimg, H, W, circular=False, out=None):
+    if out is None:
+        out = torch.empty((nimg * H * W, w.shape[0]), dtype=BF16, device=x.device)
+    _k_conv3x3_cin_small(x, w, bias, out, nimg, H, W, bool(circular))
     return out
+
+
+def _im2col3x3_c4_impl(x, cols, nimg, H, W, circular):
+    lib = load()
+    xp, cp = _ptr(x, BF16, "X"), _ptr(cols, BF16)
+    _launch("im2col_c4", dict(bytes=2.0 * nimg * H * W * (4 + 64)),
+            lambda: _check(lib.sdv_im2col3x3_c4(xp, cp, nimg, H, W, int(circular), _stream()), "sdv_im2col3x3_c4"))
+
+
+_k_im2col3x3_c4 = _defop("k_im2col3x3_c4(Tensor x, Tensor(a!) cols, int nimg, int H, int W, bool circular) -> ()", _im2col3x3_c4_impl)
 
 
 def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False, out=None):
     """3x3 pad-1 conv of a 4-channel NHWC tensor on the matrix cores: im2col to 64-wide rows + K = 64 GEMM.
     ``w_pad``: [Cout, 64] = OHWI weights [Cout, 36] zero-padded (see ``weights.conv_w_c4``)."""
-    lib = load()
     if x.shape[1] != 4:
         raise SdvHipError(f"conv3x3_c4: expected 4 input channels, got {x.shape[1]}")
     cols = torch.empty((nimg * H * W, 64), dtype=BF16, device=x.device)
-    xp, cp = _ptr(x, BF16, "X"), _ptr(cols, BF16)
-    _launch("im2col_c4", dict(bytes=2.0 * nimg * H * W * (4 + 64)),
-            lambda: _check(lib.sdv_im2col3x3_c4(xp, cp, nimg, H, W, int(circular), _stream()), "sdv_im2col3x3_c4"))
+    _k_im2col3x3_c4(x, cols, nimg, H, W, bool(circular))
     return linear(cols, w_pad, bias, out=out)
 
 
 def embed_tokens(ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
     """CLIP input embeddings: ids int64 [B, L] -> bf16 [B*L, D] = tok[ids] + pos[position]."""
-    lib = load()
     if ids.dtype != torch.int64 or ids.ndim != 2:
         raise SdvHipError("embed_tokens: ids must be int64 [B, L]")
     B, L = ids.shape
     V, D = tok.shape
     if L > pos.shape[0] or pos.shape[1] != D:
         raise SdvHipError(f"embed_tokens: {L} positions / width {D} do not fit the position table {tuple(pos.shape)}")
-    ids = ids.contiguous()
+    return _k_embed_tokens(ids.contiguous(), tok, pos)
+
+
+def _embed_tokens_impl(ids, tok, pos):
+    lib = load()
+    B, L = ids.shape
+    V, D = tok.shape
     out = torch.empty((B * L, D), dtype=BF16, device=ids.device)
     _check(lib.sdv_embed_tokens(_ptr(ids, torch.int64, "ids"), _ptr(tok, F32, "tok"), _ptr(pos, F32, "pos"), _ptr(out, BF16),
                                 B * L, L, D, V, _stream()), "sdv_embed_tokens")
     return out
 
 
+_k_embed_tokens = _defop("k_embed_tokens(Tensor ids, Tensor tok, Tensor pos) -> Tensor", _embed_tokens_impl,
+                         lambda ids, tok, pos: tok.new_empty((ids.shape[0] * ids.shape[1], tok.shape[1]), dtype=BF16))
+
+
 def rgb_u8_to_bf16_c4(img_u8: torch.Tensor, scale: float = 1.0 / 255.0) -> torch.Tensor:
     """uint8 RGB NHWC [..., 3] -> bf16 rows [npix, 4] = {r, g, b, 0} * scale."""
-    lib = load()
     if img_u8.shape[-1] != 3 or not img_u8.is_contiguous():
         raise SdvHipError("rgb_u8_to_bf16_c4: expected a contiguous [..., 3] uint8 tensor")
+    return _k_rgb_u8_to_bf16_c4(img_u8, float(scale))
+
+
+def _rgb_u8_to_bf16_c4_impl(img_u8, scale):
+    lib = load()
     npix = img_u8.numel() // 3
     out = torch.empty((npix, 4), dtype=BF16, device=img_u8.device)
     _check(lib.sdv_rgb_u8_to_bf16_c4(_ptr(img_u8, torch.uint8, "img"), _ptr(out, BF16), npix, scale, _stream()),
@@ -438,22 +551,33 @@ def rgb_u8_to_bf16_c4(img_u8: torch.Tensor, scale: float = 1.0 / 255.0) -> torch
     return out
 
 
+_k_rgb_u8_to_bf16_c4 = _defop("k_rgb_u8_to_bf16_c4(Tensor img_u8, float scale) -> Tensor", _rgb_u8_to_bf16_c4_impl,
+                              lambda img, scale: img.new_empty((img.numel() // 3, 4), dtype=BF16))
+
+
 def axpby(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float, beta: float):
     """out = alpha*a + beta*b over [rows, cols] bf16 (column slices of wider buffers allowed)."""
-    lib = load()
-    rows, cols = a.shape
     if b.shape != a.shape or out.shape != a.shape:
         raise SdvHipError("axpby: shape mismatch")
     for t in (a, b, out):
         if t.stride(1) != 1:
             raise SdvHipError("axpby: rows must be contiguous")
+    _k_axpby(a, b, out, float(alpha), float(beta))
+
+
+def _axpby_impl(a, b, out, alpha, beta):
+    lib = load()
+    rows, cols = a.shape
     _launch("axpby", dict(bytes=6.0 * rows * cols),
             lambda: _check(lib.sdv_axpby_bf16(_ptr(a, BF16, "a"), a.stride(0), _ptr(b, BF16, "b"), b.stride(0),
                                               _ptr(out, BF16, "out"), out.stride(0), rows, cols, alpha, beta, _stream()),
                            "sdv_axpby_bf16"))
 
 
-def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_u8=None, circular=False):
+_k_axpby = _defop("k_axpby(Tensor a, Tensor b, Tensor(a!) out, float alpha, float beta) -> ()", _axpby_impl)
+
+
+def _conv3x3_cout_small_impl(x, w, bias, out_f32, out_u8, nimg, H, W, out_mode, circular):
     lib = load()
     Cin = x.shape[1]
     Cout = w.shape[0]
@@ -463,16 +587,32 @@ def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_
                                                       _stream()), "sdv_conv3x3_cout_small"))
 
 
-def latent_affine(x, wpq, bias, in_scale, out, npix, Cn):
+_k_conv3x3_cout_small = _defop("k_conv3x3_cout_small(Tensor x, Tensor w, Tensor? bias, Tensor(a!)? out_f32, Tensor(b!)? out_u8, int nimg, "
+                               "int H, int W, int out_mode, bool circular) -> ()", _conv3x3_cout_small_impl)
+
+
+def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_u8=None, circular=False):
+    _k_conv3x3_cout_small(x, w, bias, out_f32, out_u8, nimg, H, W, out_mode, bool(circular))
+
+
+def _latent_affine_impl(x, wpq, bias, in_scale, out, npix, Cn):
     lib = load()
     _check(lib.sdv_latent_affine(_ptr(x, F32), _ptr(wpq, F32), _ptr(bias, F32), in_scale, _ptr(out, BF16), npix, Cn,
                                  _stream()), "sdv_latent_affine")
 
 
+_k_latent_affine = _defop("k_latent_affine(Tensor x, Tensor wpq, Tensor bias, float in_scale, Tensor(a!) out, int npix, int Cn) -> ()",
+                          _latent_affine_impl)
+
+
+def latent_affine(x, wpq, bias, in_scale, out, npix, Cn):
+    _k_latent_affine(x, wpq, bias, float(in_scale), out, npix, Cn)
+
+
 # ------------------------------------------------------------------------------------------------
 # interpolation / scheduler step
 # ------------------------------------------------------------------------------------------------
-def slerp_stats(v0, v1) -> torch.Tensor:
+def _slerp_stats_impl(v0, v1):
     lib = load()
     stats = torch.empty(3, dtype=torch.float64, device=v0.device)
     _check(lib.sdv_slerp_stats(_ptr(v0, F32, "v0"), _ptr(v1, F32, "v1"), v0.numel(), _ptr(stats), _stream()),
@@ -480,49 +620,103 @@ def slerp_stats(v0, v1) -> torch.Tensor:
     return stats
 
 
-def slerp_batch(v0, v1, stats, T, *, C_: int, HW: int, to_hwc: bool, dot_threshold: float = 0.9995, out=None):
+_k_slerp_stats = _defop("k_slerp_stats(Tensor v0, Tensor v1) -> Tensor", _slerp_stats_impl,
+                        lambda v0, v1: v0.new_empty((3,), dtype=torch.float64))
+
+
+def slerp_stats(v0, v1) -> torch.Tensor:
+    return _k_slerp_stats(v0, v1)
+
+
+def _slerp_batch_impl(v0, v1, stats, T, out, C_, HW, to_hwc, dot_threshold):
     lib = load()
-    n = T.numel()
-    if out is None:
-        out = torch.empty((n, C_ * HW), dtype=F32, device=v0.device)
-    _check(lib.sdv_slerp_batch(_ptr(v0, F32), _ptr(v1, F32), _ptr(stats, torch.float64), _ptr(T, F32), n, C_, HW,
+    _check(lib.sdv_slerp_batch(_ptr(v0, F32), _ptr(v1, F32), _ptr(stats, torch.float64), _ptr(T, F32), T.numel(), C_, HW,
                                int(to_hwc), dot_threshold, _ptr(out, F32), _stream()), "sdv_slerp_batch")
+
+
+_k_slerp_batch = _defop("k_slerp_batch(Tensor v0, Tensor v1, Tensor stats, Tensor T, Tensor(a!) out, int C_, int HW, bool to_hwc, "
+                        "float dot_threshold) -> ()", _slerp_batch_impl)
+
+
+def slerp_batch(v0, v1, stats, T, *, C_: int, HW: int, to_hwc: bool, dot_threshold: float = 0.9995, out=None):
+    if out is None:
+        out = torch.empty((T.numel(), C_ * HW), dtype=F32, device=v0.device)
+    _k_slerp_batch(v0, v1, stats, T, out, C_, HW, bool(to_hwc), float(dot_threshold))
     return out
 
 
-def lerp_batch(a, b, T, *, out_f32=None, out_bf16=None):
+def _lerp_batch_impl(a, b, T, out_f32, out_bf16):
     lib = load()
     _check(lib.sdv_lerp_batch(_ptr(a, F32), _ptr(b, F32), _ptr(T, F32), T.numel(), a.numel(), _ptr(out_f32, F32),
                               _ptr(out_bf16, BF16), _stream()), "sdv_lerp_batch")
 
 
-def cfg_ddim_step(eps, latents, x2, coefs, step_ptr, noise, guidance: float, cfg: bool, n: int):
+_k_lerp_batch = _defop("k_lerp_batch(Tensor a, Tensor b, Tensor T, Tensor(a!)? out_f32, Tensor(b!)? out_bf16) -> ()", _lerp_batch_impl)
+
+
+def lerp_batch(a, b, T, *, out_f32=None, out_bf16=None):
+    _k_lerp_batch(a, b, T, out_f32, out_bf16)
+
+
+def _cfg_ddim_step_impl(eps, latents, x2, coefs, step_ptr, noise, guidance, cfg, n):
     lib = load()
     _check(lib.sdv_cfg_ddim_step(_ptr(eps, F32), _ptr(latents, F32), _ptr(x2, BF16), _ptr(coefs, F32),
                                  _ptr(step_ptr, torch.int32), _ptr(noise, F32), guidance, int(cfg), n, _stream()),
            "sdv_cfg_ddim_step")
 
 
-def cfg_multistep_step(eps, latents, x2, hist, xsave, table, step_ptr, noise, guidance: float, cfg: bool, n: int):
-    """One fused guidance + linear-multistep scheduler update (sdv_hip.h: every scheduler besides DDIM)."""
+_k_cfg_ddim_step = _defop("k_cfg_ddim_step(Tensor eps, Tensor(a!) latents, Tensor(b!) x2, Tensor coefs, Tensor? step_ptr, Tensor? noise, "
+                          "float guidance, bool cfg, int n) -> ()", _cfg_ddim_step_impl)
+
+
+def cfg_ddim_step(eps, latents, x2, coefs, step_ptr, noise, guidance: float, cfg: bool, n: int):
+    _k_cfg_ddim_step(eps, latents, x2, coefs, step_ptr, noise, float(guidance), bool(cfg), n)
+
+
+def _cfg_multistep_step_impl(eps, latents, x2, hist, xsave, table, step_ptr, noise, guidance, cfg, n):
     lib = load()
     _check(lib.sdv_cfg_multistep_step(_ptr(eps, F32), _ptr(latents, F32), _ptr(x2, BF16), _ptr(hist, F32), _ptr(xsave, F32),
                                       _ptr(table, F32), _ptr(step_ptr, torch.int32), _ptr(noise, F32), guidance, int(cfg), n,
                                       _stream()), "sdv_cfg_multistep_step")
 
 
-def latents_to_unet_input(latents, x2, cfg: bool, n: int):
+_k_cfg_multistep_step = _defop("k_cfg_multistep_step(Tensor eps, Tensor(a!) latents, Tensor(b!) x2, Tensor(c!) hist, Tensor(d!) xsave, "
+                               "Tensor table, Tensor? step_ptr, Tensor? noise, float guidance, bool cfg, int n) -> ()",
+                               _cfg_multistep_step_impl)
+
+
+def cfg_multistep_step(eps, latents, x2, hist, xsave, table, step_ptr, noise, guidance: float, cfg: bool, n: int):
+    """One fused guidance + linear-multistep scheduler update (sdv_hip.h: every scheduler besides DDIM)."""
+    _k_cfg_multistep_step(eps, latents, x2, hist, xsave, table, step_ptr, noise, float(guidance), bool(cfg), n)
+
+
+def _latents_to_unet_input_impl(latents, x2, cfg, n):
     lib = load()
     _check(lib.sdv_latents_to_unet_input(_ptr(latents, F32), _ptr(x2, BF16), int(cfg), n, _stream()),
            "sdv_latents_to_unet_input")
 
 
-def step_counter_add(step_ptr, inc: int = 1):
+_k_latents_to_unet_input = _defop("k_latents_to_unet_input(Tensor latents, Tensor(a!) x2, bool cfg, int n) -> ()",
+                                  _latents_to_unet_input_impl)
+
+
+def latents_to_unet_input(latents, x2, cfg: bool, n: int):
+    _k_latents_to_unet_input(latents, x2, bool(cfg), n)
+
+
+def _step_counter_add_impl(step_ptr, inc):
     lib = load()
     _check(lib.sdv_step_counter_add(_ptr(step_ptr, torch.int32), inc, _stream()), "sdv_step_counter_add")
 
 
-def timestep_embedding(ts, dim: int, flip: bool, freq_shift: float):
+_k_step_counter_add = _defop("k_step_counter_add(Tensor(a!) step_ptr, int inc) -> ()", _step_counter_add_impl)
+
+
+def step_counter_add(step_ptr, inc: int = 1):
+    _k_step_counter_add(step_ptr, inc)
+
+
+def _timestep_embedding_impl(ts, dim, flip, freq_shift):
     lib = load()
     out = torch.empty((ts.numel(), dim), dtype=F32, device=ts.device)
     _check(lib.sdv_timestep_embedding(_ptr(ts, F32), ts.numel(), dim, int(flip), freq_shift, _ptr(out), _stream()),
@@ -530,7 +724,15 @@ def timestep_embedding(ts, dim: int, flip: bool, freq_shift: float):
     return out
 
 
-def linear_small(x, w, b=None, add=None, silu_in=False):
+_k_timestep_embedding = _defop("k_timestep_embedding(Tensor ts, int dim, bool flip, float freq_shift) -> Tensor", _timestep_embedding_impl,
+                               lambda ts, dim, flip, fs: ts.new_empty((ts.numel(), dim), dtype=F32))
+
+
+def timestep_embedding(ts, dim: int, flip: bool, freq_shift: float):
+    return _k_timestep_embedding(ts, dim, bool(flip), float(freq_shift))
+
+
+def _linear_small_impl(x, w, b, add, silu_in):
     lib = load()
     M, K = x.shape
     N = w.shape[0]
@@ -540,24 +742,49 @@ def linear_small(x, w, b=None, add=None, silu_in=False):
     return out
 
 
-def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+_k_linear_small = _defop("k_linear_small(Tensor x, Tensor w, Tensor? b, Tensor? add, bool silu_in) -> Tensor", _linear_small_impl,
+                         lambda x, w, b, add, silu_in: x.new_empty((x.shape[0], w.shape[0]), dtype=F32))
+
+
+def linear_small(x, w, b=None, add=None, silu_in=False):
+    return _k_linear_small(x, w, b, add, bool(silu_in))
+
+
+def _permute_f32_impl(x, to_nhwc):
     lib = load()
-    n, c, h, w = x.shape
-    out = torch.empty((n, h, w, c), dtype=F32, device=x.device)
-    _check(lib.sdv_nchw_to_nhwc_f32(_ptr(x.contiguous(), F32), _ptr(out), n, c, h * w, _stream()), "sdv_nchw_to_nhwc_f32")
+    if to_nhwc:
+        n, c, h, w = x.shape
+        out = torch.empty((n, h, w, c), dtype=F32, device=x.device)
+        _check(lib.sdv_nchw_to_nhwc_f32(_ptr(x.contiguous(), F32), _ptr(out), n, c, h * w, _stream()), "sdv_nchw_to_nhwc_f32")
+    else:
+        n, h, w, c = x.shape
+        out = torch.empty((n, c, h, w), dtype=F32, device=x.device)
+        _check(lib.sdv_nhwc_to_nchw_f32(_ptr(x.contiguous(), F32), _ptr(out), n, c, h * w, _stream()), "sdv_nhwc_to_nchw_f32")
     return out
+
+
+_k_permute_f32 = _defop("k_permute_f32(Tensor x, bool to_nhwc) -> Tensor", _permute_f32_impl,
+                        lambda x, to_nhwc: x.new_empty((x.shape[0], x.shape[2], x.shape[3], x.shape[1]) if to_nhwc else
+                                                       (x.shape[0], x.shape[3], x.shape[1], x.shape[2]), dtype=F32))
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    return _k_permute_f32(x, True)
 
 
 def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
-    lib = load()
-    n, h, w, c = x.shape
-    out = torch.empty((n, c, h, w), dtype=F32, device=x.device)
-    _check(lib.sdv_nhwc_to_nchw_f32(_ptr(x.contiguous(), F32), _ptr(out), n, c, h * w, _stream()), "sdv_nhwc_to_nchw_f32")
-    return out
+    return _k_permute_f32(x, False)
 
 
-def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+def _f32_to_bf16_impl(x):
     lib = load()
     out = torch.empty(x.shape, dtype=BF16, device=x.device)
     _check(lib.sdv_f32_to_bf16(_ptr(x.contiguous(), F32), _ptr(out), x.numel(), _stream()), "sdv_f32_to_bf16")
     return out
+
+
+_k_f32_to_bf16 = _defop("k_f32_to_bf16(Tensor x) -> Tensor", _f32_to_bf16_impl, lambda x: x.new_empty(x.shape, dtype=BF16))
+
+
+def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    return _k_f32_to_bf16(x)

@@ -2,12 +2,18 @@
 (``torch.library.custom_op``), the boundary BASELINE.json's north_star names ("Python host code calling hand-written CDNA4
 HIP kernels through PyTorch-ROCm custom ops"; SURVEY.md 8b proposes exactly this op list).
 
-Each op is a thin, typed front of the ctypes binding in ``hip.py`` (which passes ``data_ptr()`` + the current HIP stream to
-the C ABI of include/sdv_hip.h): same kernels, same launches, plus what the dispatcher wants - a schema, device checks and a
-fake (meta) implementation, so the ops compose with ``torch.compile`` / FakeTensor shape propagation and show up by name in
-the PyTorch profiler.  The engines call ``hip.*`` directly (one Python frame less per launch inside the per-step graph
-capture); these ops are the public PyTorch-level entry points to the same code and are what an ATen-based caller - e.g. a
-diffusers model patched layer by layer - would use.  There is NO CPU implementation: a CPU tensor raises ``SdvHipError``.
+Two layers, both in the ``sdv`` namespace:
+
+* ``torch.ops.sdv.k_*`` (registered in ``hip.py``, 23 ops): ONE op per kernel launch of the C ABI (include/sdv_hip.h) - schema with
+  the mutated outputs annotated, an implementation that passes ``data_ptr()`` + the current HIP stream to libsdv_hip.so, a
+  Meta kernel.  **The product runs on these**: every wrapper in ``hip.py`` that ``engine.py`` / ``pipeline.py`` / ``text.py`` /
+  ``esrgan.py`` call packs its arguments and calls the op (``tests/test_host.py::test_every_launch_is_a_torch_custom_op`` checks
+  that nothing else touches ctypes), inside hipGraph capture as well.
+* the ops below: tensor-in / tensor-out conveniences with PyTorch-style signatures (``linear``, ``conv3x3``, ``attention`` ...)
+  built on the first layer - what an ATen-based caller, e.g. a diffusers model patched layer by layer, would use; they compose with
+  ``torch.compile`` / FakeTensor shape propagation and show up by name in the PyTorch profiler.
+
+There is NO CPU implementation in either layer: a CPU tensor raises ``SdvHipError``.
 
 What each op replaces in the reference is cited on the C declaration it forwards to (include/sdv_hip.h):
     sdv::linear / sdv::conv3x3 / sdv::upsample_conv3x3 / sdv::attention / sdv::group_norm / sdv::layer_norm
