@@ -23,6 +23,10 @@ def timed(fn, reps=2):
     return s.elapsed_time(e) / reps
 
 
+import os
+ORDERS = tuple(int(x) for x in os.environ.get("SDV_AB_ORDERS", "0,1").split(","))      # e.g. SDV_AB_ORDERS=2,0: unfused vs fused
+
+
 def main():
     pmc = len(sys.argv) > 1 and sys.argv[1] == "pmc"
     nimg = 256 if pmc or len(sys.argv) < 2 else int(sys.argv[1])
@@ -58,22 +62,23 @@ def main():
             torch.cuda.synchronize()
             print(label, "order", order, "done")
             continue
-        run(0)
+        A, B = ORDERS
+        run(A)
         torch.cuda.synchronize()
         ref = out.float().clone()
-        run(1)
+        run(B)
         torch.cuda.synchronize()
         dev_rel = float((out.float() - ref).norm() / ref.norm())
         assert dev_rel < 3e-3, (label, dev_rel)        # same products, another summation order: bf16 rounding flips only
-        ms = {0: [], 1: []}
+        ms = {A: [], B: []}
         for _ in range(rounds):
-            for o in (0, 1):
+            for o in (A, B):
                 ms[o].append(timed(lambda: run(o)))
         flops = 18.0 * M * (c1 + c2) * cout
         row = [f"order {o}: {flops / statistics.median(ms[o]) / 1e9:6.0f} ({flops / max(ms[o]) / 1e9:5.0f}..{flops / min(ms[o]) / 1e9:5.0f})"
-               for o in (0, 1)]
+               for o in (A, B)]
         print(f"{label:26s} M={M:8d}  " + "   ".join(row) +
-              f"   channel-major/tap-major = {statistics.median(ms[0]) / statistics.median(ms[1]):.3f}   (rel-L2 between the two {dev_rel:.1e})")
+              f"   order {B} / order {A} = {statistics.median(ms[A]) / statistics.median(ms[B]):.3f}   (rel-L2 between the two {dev_rel:.1e})")
         del x, w, out, res, ref
 
 
