@@ -100,7 +100,10 @@ typedef struct sdv_gemm_args {
      * multiples).  v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate, bf16 output; pass the product of the two per-tensor
      * dequantisation scales as `alpha`.  BASELINE.json configs[4] ("SD-v1-4 fp8"): the reference has no fp8 line of its own
      * (its dtype is whatever torch_dtype says, stable_diffusion_pipeline.py:840-858); here the ResBlock convolutions take fp8
-     * activations written by sdv_groupnorm_apply(Y8, q_scale) and fp8 weights.  Tiles 1 / 6 / 7 / 9. */
+     * activations written by sdv_groupnorm_apply(Y8, q_scale) and fp8 weights.  Tiles 1 / 6 / 7 / 9.
+     * fp8 == 2: the same operands on CDNA4's block-scaled form v_mfma_scale_f32_32x32x64_f8f6f4 with every block scale 1.0
+     * (E8M0 127) - 64 K values per instruction at twice the bf16 / plain fp8 rate, two 64-wide K images per barrier interval;
+     * tap-major K order only.  Same products as fp8 == 1: the results differ by the fp32 summation order at most. */
     int32_t fp8;
     /* out_mode != 0: the output leaves in another type than bf16 (C may then be NULL), N <= 32, 4-wave tiles only (auto: 256x32):
      *   1  out_f32 [M][ldc] fp32                                    (UNet conv_out 320 -> 4: the noise prediction stays fp32)

@@ -48,17 +48,25 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     constexpr int BN = WN * TN * 32;
     // FEAT 8: fp8 (OCP e4m3) operands - X and W are bytes, the MFMA is v_mfma_f32_32x32x16_fp8_fp8 (bf16 rate, half the
     // LDS-DMA and LDS-read bytes per MFMA), accumulation fp32, output bf16; the per-tensor dequantisation scale is `alpha`.
-    constexpr int ES = FEAT == 8 ? 1 : 2;   // operand element size in bytes
+    // FEAT 9: the same operands on the block-scaled form v_mfma_scale_f32_32x32x64_f8f6f4 with every block scale = 1 (E8M0 127):
+    // 64 K values per instruction at TWICE the bf16 / plain-fp8 MFMA rate.  A K slab is a PAIR of the fp8 tile's 64-byte-row
+    // images (one per k-step; the second one of the K loop's last slab may be "dead": fetched through a zero-length buffer
+    // descriptor, i.e. zeros that cost no memory traffic), so LDS-DMA pieces, fragment reads and barriers per MFMA cycle are
+    // those of the bf16 tile, at twice the FLOPs.
+    constexpr bool MX = FEAT == 9;
+    constexpr int ES = (FEAT == 8 || MX) ? 1 : 2;   // operand element size in bytes
     constexpr int ROWB = BK * ES;           // bytes per LDS row (128 or 64)
     constexpr int CPRW = ROWB / 16;         // 16-byte chunks per row (8 or 4)
     constexpr int RPI = 1024 / ROWB;        // rows one wave-instruction (1 KiB) moves (8 or 16)
-    constexpr int TILE_BYTES = (BM + BN) * ROWB;
+    constexpr int HALF_BYTES = (BM + BN) * ROWB;          // one 64-wide K image of both panels
+    constexpr int TILE_BYTES = (MX ? 2 : 1) * HALF_BYTES;
     constexpr int GX = BM / RPI, GW = BN / RPI;                    // 1-KiB row groups of the X / W panels
     constexpr int NX = (GX + NWV - 1) / NWV, NW = (GW + NWV - 1) / NWV;
     constexpr int KSTEPS = BK / 16;
     static_assert(BM % RPI == 0 && BN % RPI == 0, "panels must be whole 1-KiB groups");
     static_assert(BK == 64 || BK == 32, "BK");
     static_assert(FEAT != 8 || (BK == 64 && NST == 2), "fp8 tiles: 64 elements (64 bytes) per K tile, double buffered");
+    static_assert(!MX || (BK == 64 && NST == 2), "MX fp8 tiles: two 64-element images per K tile, double buffered");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -121,6 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     int tap = 0, srcsel = 0, seg_left = 0;
     bool dead_stream = false;   // ring tiles, last tile of a workgroup: the pieces past the tile's last K slab read nothing
     int kx = 0;   // scalar byte offset inside the current X source
+    int halves_left = 0;   // MX: 64-wide K images of the current tile not yet staged (0 -> the slab's second image is dead)
     int kwb = 0;  // scalar byte offset along the W rows (all taps and sources are contiguous in K)
 
     // channel-major K order (sdv_hip.h k_order 1) - an EXPERIMENT kept selectable: it cuts the conv's fabric reads 3.2x and is
@@ -205,6 +214,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         kx = 0;
         kwb = 0;
         dead_stream = false;
+        halves_left = (K / BK) * (CONV ? (p.mode == 4 ? 4 : 9) : 1);
     };
 
     // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
@@ -285,7 +295,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 return;
             }
         }
-        if (seg_left == 0) new_segment();
+#pragma unroll
+        for (int hf = 0; hf < (MX ? 2 : 1); ++hf, base += HALF_BYTES) {
+        // MX: an odd number of 64-wide K images leaves the last slab's SECOND image dead - every piece of it gets an offset
+        // past the descriptor's range (the range check answers with zeros, nothing is fetched), no bookkeeping advances
+        const bool dead = MX && hf == 1 && halves_left == 0;
+        const unsigned dmask = dead ? kOOB : 0u;
+        if (!dead && seg_left == 0) new_segment();
         const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
         if (issue) {
 #pragma unroll
@@ -293,16 +309,18 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             const int g = wave + NWV * i;
             if (GX % NWV == 0 || g < GX)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(base + g * 1024), 16,
-                                                         (int)xvo[i], kx, 0, 0);
+                                                         (int)(MX && hf == 1 ? xvo[i] | dmask : xvo[i]), kx, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int g = wave + NWV * i;
             if (GW % NWV == 0 || g < GW)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024),
-                                                         16, (int)wvo[i], kwb, 0, 0);
+                                                         16, (int)(MX && hf == 1 ? wvo[i] | dmask : wvo[i]), kwb, 0, 0);
         }
         }
+        if (!dead) {
+        --halves_left;
         kx += ROWB;
         kwb += ROWB;
         if (--seg_left == 0) {
@@ -312,6 +330,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 srcsel = 0;
                 ++tap;
             }
+        }
+        }
         }
     };
 
@@ -336,6 +356,41 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     constexpr bool kPipeFrags = TM * TN >= 8;   // big tiles: 1 workgroup / CU, hide LDS latency inside the wave
     auto compute = [&](int buf) {
         const char* base = smem + buf * SLOT;
+        if constexpr (MX) {
+            // K image s of the slab feeds ONE 64-deep MFMA per (n, m) tile: lane (l31, lhi) supplies the 16-byte chunks lhi and
+            // 2 + lhi of its row (the two fragment reads of the fp8 tile).  Both operands walk K in that same order, so the
+            // contraction is unchanged whatever order the instruction assigns to a lane's 32 bytes.
+            typedef int __attribute__((ext_vector_type(8))) i32x8_t;
+            constexpr int kOne = 0x7f7f7f7f;   // E8M0 127 = 2^0 in every scale byte
+            auto frag = [&](const char* hb, int row0) __attribute__((always_inline)) -> i32x8_t {
+                const u32x4_t lo = *(const u32x4_t*)(hb + row0 * ROWB + frag_off[0]);
+                const u32x4_t hi = *(const u32x4_t*)(hb + row0 * ROWB + frag_off[1]);
+                return i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            };
+            // Low-pressure order (the 256 x 320 tile has ~90 VGPRs besides its 160 accumulators, and an MX operand is an aligned
+            // 8-register tuple): the X fragments of one K image (TM x 8 registers), ONE W fragment in use and the next one in
+            // flight - its two reads are issued ahead of the TM MFMAs of the current one, which cover their latency.
+            i32x8_t xa[2][TM];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) xa[0][mt] = frag(base, xrow0 + mt * 32);
+            i32x8_t wcur = frag(base, wrow0);
+#pragma unroll
+            for (int st = 0; st < 2 * TN; ++st) {
+                const int s = st / TN, nt = st % TN;
+                i32x8_t wnext = wcur;
+                if (st + 1 < 2 * TN) wnext = frag(base + ((st + 1) / TN) * HALF_BYTES, wrow0 + ((st + 1) % TN) * 32);
+                if (st == TN - 1) {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) xa[1][mt] = frag(base + HALF_BYTES, xrow0 + mt * 32);
+                }
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcur, xa[s][mt], acc[nt][mt], 0, 0, 0, kOne, 0, kOne);
+                __builtin_amdgcn_sched_barrier(0);
+                wcur = wnext;
+            }
+            return;
+        }
         if constexpr (ES == 1) {
             // fp8: a K tile is 64 bytes per row = four 16-byte chunks.  One ds_read_b128 of chunk 2j + lhi yields two
             // 8-byte MFMA operands, used for k-steps 2j and 2j+1 (both operands walk K in the same permuted order, so the
@@ -405,7 +460,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     };
 
     const int ntaps = CONV ? (p.mode == 4 ? 4 : 9) : 1;
-    const int nkt = (K / BK) * ntaps;
+    const int nkt = MX ? ((K / BK) * ntaps + 1) / 2 : (K / BK) * ntaps;   // (MX: two 64-wide K images per slab)
     // tile walk state: `vb` = the tile being computed, `slot0` = the LDS slot its first K slab is in, `landed` = that slab
     // was fetched (and waited for) during the tile before
     int vb = blockIdx.x;
@@ -792,7 +847,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 constexpr int PP = (TN + NPT - 1) / NPT;                    // passes per m-tile
                 constexpr int NP = TM * PP;
                 constexpr int MAXIT = F32 ? 2 : 4;                          // 64-lane iterations of the row-major phase
-                constexpr int DEPTH = (FEAT == 0 || FEAT == 8) ? 2 : 1, RING = DEPTH + 1;   // residual rows are fetched DEPTH passes ahead
+                constexpr int DEPTH = (FEAT == 0 || FEAT == 8 || FEAT == 9) ? 2 : 1, RING = DEPTH + 1;   // residual rows are fetched DEPTH passes ahead
                 // geometry of pass pi
                 auto p_mt = [&](int pi) { return pi / PP; };
                 auto p_nt0 = [&](int pi) { return (pi % PP) * NPT; };
@@ -1198,7 +1253,7 @@ int num_cus() {
 template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT = 0>
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int TILE_BYTES = (BM + BN) * BK * (FEAT == 8 ? 1 : 2);
+    constexpr int TILE_BYTES = (BM + BN) * BK * (FEAT == 8 ? 1 : 2);   // (FEAT 9: two 64-byte-row images = the bf16 tile's bytes)
     constexpr bool PERSIST = WM * WN == 8 && (NST == 2 || !CONV);      // (see the kernel)
     constexpr int SLABS = (NST > 2 ? 1 : 2) * WM * WN * 32 * 144;      // the epilogue's staging slabs (alias ONE K-slab buffer)
     constexpr int SLOT = PERSIST && SLABS > TILE_BYTES ? SLABS : TILE_BYTES;
@@ -1231,6 +1286,9 @@ int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
     if (a.fp8) {
         if constexpr (LN_OK && BK == 64 && NST == 2) {   // the same four 8-wave / 4-wave tiles carry the fp8 variants
             SDV_REQUIRE(!a.ln_side && !a.stats_out, "sdv_gemm_bf16: fp8 operands do not combine with the LayerNorm fold");
+            if (a.fp8 == 2)
+                return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 9>(a, stream)
+                                   : launch_igemm_t<WM, WN, TM, TN, BK, true, NST, 9>(a, stream);
             return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 8>(a, stream)
                                : launch_igemm_t<WM, WN, TM, TN, BK, true, NST, 8>(a, stream);
         }
@@ -1293,7 +1351,8 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     }
     SDV_REQUIRE(a.C1 % 64 == 0 && a.C1 > 0 && a.C1 <= a.K, "sdv_gemm_bf16: C1=%d must be a multiple of 64 in (0,K]", a.C1);
     SDV_REQUIRE(a.ldx % 8 == 0 && a.ldx2 % 8 == 0 && a.ldw % 8 == 0, "sdv_gemm_bf16: ldx/ldx2/ldw must be multiples of 8");
-    SDV_REQUIRE(a.fp8 == 0 || a.fp8 == 1, "sdv_gemm_bf16: bad fp8 flag %d", a.fp8);
+    SDV_REQUIRE(a.fp8 >= 0 && a.fp8 <= 2, "sdv_gemm_bf16: bad fp8 flag %d", a.fp8);
+    if (a.fp8 == 2) a.k_order = 0;   // (channel-major K order exists for the bf16 / plain fp8 tiles only)
     if (a.fp8) SDV_REQUIRE(a.ldx % 16 == 0 && a.ldx2 % 16 == 0 && a.ldw % 16 == 0, "sdv_gemm_bf16: fp8 rows must be 16-byte multiples");
     if (a.mode != 0) {
         SDV_REQUIRE(a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "sdv_gemm_bf16: bad conv geometry");

@@ -140,6 +140,7 @@ FP8 = torch.float8_e4m3fn      # OCP e4m3, what gfx950's fp8 MFMA and converters
 FP8_MAX = 448.0
 
 _zero_pages = {}
+FP8_MX = int(os.environ.get("SDV_FP8_MX", "1"))            # developer knob for A/B: 0 = fp8 operands on the plain (bf16-rate) fp8 MFMA
 K_ORDER = int(os.environ.get("SDV_CONV_K_ORDER", "-1"))    # developer knob for A/B (tools/conv_order_ab.py); -1 = library default
 
 # Optional launch observer used by bench.py's roofline pass: called as hook(kind, info_dict, launch_fn).  The
@@ -203,7 +204,8 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
     if fp8:
         if w.dtype != FP8 or (x2 is not None and x2.dtype != FP8) or g["x_off"] or g["w_off"]:
             raise SdvHipError("gemm: fp8 activations need fp8 weights (and no operand offsets)")
-        a.fp8 = 1
+        # 2 = the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 form (twice the MFMA rate; sdv_hip.h), 1 = v_mfma_f32_32x32x16_fp8_fp8
+        a.fp8 = 2 if FP8_MX else 1
         a.X, a.X2, a.W = _ptr(x, FP8, "X"), _ptr(x2, FP8, "X2"), _ptr(w, FP8, "W")
     else:
         a.X = _ptr(x, BF16, "X") + 2 * g["x_off"]

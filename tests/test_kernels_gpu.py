@@ -794,10 +794,13 @@ def _q8(t, amax=None):
     return (t / s).to(torch.float8_e4m3fn), s
 
 
+@pytest.mark.parametrize("mx", [0, 1])
 @pytest.mark.parametrize("tile", [0, 1, 6, 7, 9])
-def test_gemm_and_conv_fp8_operands(hip, dev, tile):
-    """sdv_gemm_bf16 with fp8 = 1 (v_mfma_f32_32x32x16_fp8_fp8): against fp32 arithmetic on the SAME quantised values -
-    what remains is fp32 accumulation order and the bf16 output rounding, i.e. the bf16 kernels' own tolerance."""
+def test_gemm_and_conv_fp8_operands(hip, dev, tile, mx, monkeypatch):
+    """sdv_gemm_bf16 with fp8 = 1 (v_mfma_f32_32x32x16_fp8_fp8) and fp8 = 2 (the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4
+    with unit scales, twice the rate): against fp32 arithmetic on the SAME quantised values - what remains is fp32
+    accumulation order and the bf16 output rounding, i.e. the bf16 kernels' own tolerance."""
+    monkeypatch.setattr(hip, "FP8_MX", mx)
     M, N, K = 777, 640, 1280
     x, w = rnd((M, K), dev, 120), rnd((N, K), dev, 121, K ** -0.5)
     bias, res = rnd((N,), dev, 122), rnd((M, N), dev, 123)
@@ -810,7 +813,7 @@ def test_gemm_and_conv_fp8_operands(hip, dev, tile):
     full = x @ w.T + bias + res
     from conftest import report
     if tile == 0:
-        report(f"fp8 GEMM vs unquantised fp32: rel-L2 {rel_l2(out.float(), full):.2e}")
+        report(f"fp8 GEMM (form {1 + mx}) vs unquantised fp32: rel-L2 {rel_l2(out.float(), full):.2e}")
     # conv3x3 (two-source concat, residual), NHWC
     n, H, W, C1, C2, Cout = 2, 16, 16, 128, 64, 320
     xa, xb = rnd((n, H, W, C1), dev, 124), rnd((n, H, W, C2), dev, 125)
@@ -825,6 +828,53 @@ def test_gemm_and_conv_fp8_operands(hip, dev, tile):
                       alpha=sa * swc, tile=tile)
     ref = conv_ref(torch.cat([xa8.float(), xb8.float()], -1) * sa, wc8.float() * swc, bc, 1, False) + rc
     assert rel_l2(out.float().reshape(ref.shape), ref) < MFMA_TOL
+
+
+@pytest.mark.parametrize("tile", [0, 1, 6, 7, 9])
+def test_fp8_mx_form_matches_float64_on_exact_products(hip, dev, tile, monkeypatch):
+    """fp8 = 2 on shapes whose number of 64-wide K images is ODD (the K loop's last slab carries a dead image: K = 320 dense, 5
+    images; 9 x 320 / 64 = 45 for the ResBlock conv of the 64^2 level; K = 64: one live image in all) and EVEN (K = 640), with
+    enough tiles that the 8-wave tiles walk persistently.  e4m3 x e4m3 products are exact in fp32, so against float64 on the
+    same bytes only the accumulation (and the bf16 output rounding) remains.  Bound: half a bf16 ulp + 4e-5 sum|x w| - the
+    64-deep block-scaled MFMA does NOT accumulate like an fp32 FMA chain (measured on MI355X: worst element 1.3e-5 sum|x w|
+    at K = 320, where the bf16 and plain-fp8 MFMAs stay below 1e-5; both forms are reported side by side).  An operand in the
+    wrong K position, a K image counted twice or dropped, or a dead image that is not zero all show up at 1e-1."""
+    from conftest import report
+
+    def worst_dense(form, M, N, K):
+        monkeypatch.setattr(hip, "FP8_MX", form - 1)
+        x8, sx = _q8(rnd((M, K), dev, 140 + K))
+        w8, sw = _q8(rnd((N, K), dev, 141 + K, K ** -0.5))
+        out = hip.linear(x8, w8, None, alpha=sx * sw, tile=tile).double()
+        assert torch.equal(out, hip.linear(x8, w8, None, alpha=sx * sw, tile=tile).double())       # (deterministic across launches)
+        xd, wd = x8.double() * sx, w8.double() * sw
+        ref = xd @ wd.T
+        err = ((out - ref).abs() - ref.abs() * 2.0 ** -8).clamp_min(0.0)            # what half a bf16 ulp does not explain ...
+        return float((err / (xd.abs() @ wd.abs().T + 1e-30)).max())                # ... in units of sum|x w|
+
+    def worst_conv(form, n, H, W, Cin, Cout):
+        monkeypatch.setattr(hip, "FP8_MX", form - 1)
+        x8, sx = _q8(rnd((n, H, W, Cin), dev, 150 + Cin))
+        wc8, sw = _q8(rnd((Cout, Cin, 3, 3), dev, 151 + Cin, (9 * Cin) ** -0.5))
+        w_ohwi = wc8.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+        out = hip.conv3x3(x8.reshape(-1, Cin), w_ohwi, None, nimg=n, H=H, W=W, alpha=sx * sw, tile=tile).double().reshape(n, H, W, Cout)
+        xd, wd = x8.double() * sx, wc8.double() * sw
+        ref = F.conv2d(xd.permute(0, 3, 1, 2), wd, None, 1, 1).permute(0, 2, 3, 1)
+        mag = F.conv2d(xd.abs().permute(0, 3, 1, 2), wd.abs(), None, 1, 1).permute(0, 2, 3, 1)
+        err = ((out - ref).abs() - ref.abs() * 2.0 ** -8).clamp_min(0.0)
+        return float((err / (mag + 1e-30)).max())
+
+    for shape in [(70000, 320, 320), (4099, 960, 640), (333, 64, 64)]:
+        e1, e2 = worst_dense(1, *shape), worst_dense(2, *shape)
+        if tile == 0:
+            report(f"fp8 dense {shape}: accumulation error beyond the output rounding, worst element: plain fp8 {e1:.1e}, MX form {e2:.1e} (x sum|xw|)")
+        assert e1 <= 4e-5 and e2 <= 4e-5, f"dense {shape} tile {tile}: {e1:.2e} / {e2:.2e} sum|xw|"
+    # the SD-1.4 64^2-level ResBlock conv shape (Cin = 320: 45 K images, 96 tiles of 256 rows), and a 960-channel one
+    for shape in [(6, 64, 64, 320, 320), (2, 32, 32, 960, 640)]:
+        e1, e2 = worst_conv(1, *shape), worst_conv(2, *shape)
+        if tile == 0:
+            report(f"fp8 conv {shape}: worst element: plain fp8 {e1:.1e}, MX form {e2:.1e} (x sum|xw|)")
+        assert e1 <= 4e-5 and e2 <= 4e-5, f"conv {shape} tile {tile}: {e1:.2e} / {e2:.2e} sum|xw|"
 
 
 def test_groupnorm_fp8_output(hip, dev):
