@@ -835,10 +835,11 @@ def test_fp8_mx_form_matches_float64_on_exact_products(hip, dev, tile, monkeypat
     """fp8 = 2 on shapes whose number of 64-wide K images is ODD (the K loop's last slab carries a dead image: K = 320 dense, 5
     images; 9 x 320 / 64 = 45 for the ResBlock conv of the 64^2 level; K = 64: one live image in all) and EVEN (K = 640), with
     enough tiles that the 8-wave tiles walk persistently.  e4m3 x e4m3 products are exact in fp32, so against float64 on the
-    same bytes only the accumulation (and the bf16 output rounding) remains.  Bound: half a bf16 ulp + 4e-5 sum|x w| - the
-    64-deep block-scaled MFMA does NOT accumulate like an fp32 FMA chain (measured on MI355X: worst element 1.3e-5 sum|x w|
-    at K = 320, where the bf16 and plain-fp8 MFMAs stay below 1e-5; both forms are reported side by side).  An operand in the
-    wrong K position, a K image counted twice or dropped, or a dead image that is not zero all show up at 1e-1."""
+    same bytes only the accumulation (and the bf16 output rounding) remains.  Bound: half a bf16 ulp + 4e-5 sum|x w| - the fp8
+    MFMAs do not accumulate like an fp32 FMA chain (measured on MI355X: worst element 1.3e-5 sum|x w| at K = 320 for BOTH
+    forms, to the digit - the two instructions sum the same products the same way; the bf16 MFMA stays below 1e-5; both forms
+    are reported side by side).  An operand in the wrong K position, a K image counted twice or dropped, or a dead image that
+    is not zero all show up at 1e-1."""
     from conftest import report
 
     def worst_dense(form, M, N, K):
