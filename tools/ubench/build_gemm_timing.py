@@ -34,15 +34,34 @@ PATCHES = [
     ("namespace {\n", "namespace {\n" + MACRO),
     ("    extern __shared__ __attribute__((aligned(16))) char smem[];\n",
      "    extern __shared__ __attribute__((aligned(16))) char smem[];\n    int tstamp = 0;\n    SDV_STAMP(0);\n"),
-    ("            __syncthreads();   // the vectors are staged AND every wave has left the K loop",
-     "            SDV_STAMP(5);\n            __syncthreads();   SDV_STAMP(3);   // the vectors are staged AND every wave has left the K loop"),
+    ("                __builtin_amdgcn_s_barrier();\n                asm volatile(\"\" ::: \"memory\");\n                if constexpr (FEAT == 3) rowacc[lane_e] = 0.f;\n",
+     "                SDV_STAMP(5);\n                __builtin_amdgcn_s_barrier();\n                asm volatile(\"\" ::: \"memory\");\n                SDV_STAMP(3);\n"
+     "                if constexpr (FEAT == 3) rowacc[lane_e] = 0.f;\n"),
     ("        kloop();\n", "        SDV_STAMP(1);\n        kloop();\n        SDV_STAMP(2);\n"),
     ("        epilogue();\n", "        epilogue();\n        SDV_STAMP(4);\n"),
     ('extern "C" int sdv_gemm_set_persistent(int on) {', ENTRY + 'extern "C" int sdv_gemm_set_persistent(int on) {'),
 ]
 
 
-def stamped_source(text: str) -> str:
+# Timing-only what-if variants of the epilogue (WRONG results, never shipped): `build_gemm_timing.py <wg> whatif=<name>[,<name>]`
+WHATIF = {
+    # no global stores at all (the values stay live): what the LDS staging + conversions cost on their own
+    "nostore": [("                        __builtin_amdgcn_raw_buffer_store_b128(packed, rs_c, (int)vo_c, soff(pi, p.ldc), 0);\n",
+                 "                        asm volatile(\"\" ::\"v\"(packed), \"v\"(vo_c));\n")],
+    # no idle slots behind the stores (the gfx950 store hazard is then live: results are wrong)
+    "nonop": [('                        asm volatile("s_nop 7" ::"v"(packed), "v"(vo_c) : "memory");\n',
+               '                        asm volatile("" ::"v"(packed), "v"(vo_c) : "memory");\n')],
+    # no residual loads (the fp32 pass structure stays)
+    "nores": [("                            rres[pi % RING][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)b, soff(pi, p.ldr), 0);\n",
+               "                            rres[pi % RING][it] = u32x4_t{(unsigned)b, 0u, 0u, 0u};\n")],
+}
+
+
+def stamped_source(text: str, whatif=()) -> str:
+    for w in whatif:
+        for old, new in WHATIF[w]:
+            assert text.count(old) == 1, f"build_gemm_timing: what-if anchor {old[:60]!r} occurs {text.count(old)} times"
+            text = text.replace(old, new)
     for old, new in PATCHES:
         assert text.count(old) == 1, f"build_gemm_timing: anchor {old[:50]!r} occurs {text.count(old)} times - update the patch"
         text = text.replace(old, new)
@@ -53,13 +72,15 @@ def main():
     b.build()
     src = b.CSRC / "sdv_gemm.hip"
     wg = sys.argv[1] if len(sys.argv) > 1 else "0"
-    extra = sys.argv[2:]          # extra -D flags
+    whatif = [w for a in sys.argv[2:] if a.startswith("whatif=") for w in a[7:].split(",") if w]
+    extra = [a for a in sys.argv[2:] if not a.startswith("whatif=")]          # extra -D flags
     here = Path(__file__).resolve().parent
-    name = "libsdv_gemm_timing.so" if wg != "notiming" else "libsdv_gemm_dbg%s.so" % "".join(c for c in "".join(extra) if c.isdigit())
+    name = ("libsdv_gemm_timing%s.so" % "".join("_" + w for w in whatif)) if wg != "notiming" else \
+        "libsdv_gemm_dbg%s.so" % "".join(c for c in "".join(extra) if c.isdigit())
     others = [b.OBJDIR / f"{s.stem}.o" for s in b.sources() if s.name != src.name]
     with tempfile.TemporaryDirectory() as tmp:
         patched = Path(tmp) / "sdv_gemm_timing.hip"
-        patched.write_text(stamped_source(src.read_text()) if wg != "notiming" else src.read_text())
+        patched.write_text(stamped_source(src.read_text(), whatif) if wg != "notiming" else src.read_text())
         obj = Path(tmp) / "gemm_timing.o"
         subprocess.run([b.hipcc(), *b.FLAGS, *b.FAST_FLAGS, *b.EXTRA_FLAGS[src.name], "-I", str(b.CSRC),
                         *([f"-DSDV_GEMM_TIMING={wg}"] if wg != "notiming" else []), *extra, "-DSDV_GEMM_ONLY_TILE6", "-c", str(patched),
