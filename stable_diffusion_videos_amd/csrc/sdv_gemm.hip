@@ -368,26 +368,28 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 return i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
             };
             // Low-pressure order (the 256 x 320 tile has ~90 VGPRs besides its 160 accumulators, and an MX operand is an aligned
-            // 8-register tuple): the X fragments of one K image (TM x 8 registers), ONE W fragment in use and the next one in
-            // flight - its two reads are issued ahead of the TM MFMAs of the current one, which cover their latency.
+            // 8-register tuple): the X fragments of a K image (TM x 8 registers, the second image's are read AH steps before
+            // their first use), ONE W fragment in use and AH more in flight behind the TM MFMAs of each step.
+            constexpr int AH = 2;   // W fragments in flight ahead of the one the MFMAs use (1 / 2 / 3 measured equal on MI355X)
             i32x8_t xa[2][TM];
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) xa[0][mt] = frag(base, xrow0 + mt * 32);
-            i32x8_t wcur = frag(base, wrow0);
+            auto wfrag = [&](int st) __attribute__((always_inline)) { return frag(base + (st / TN) * HALF_BYTES, wrow0 + (st % TN) * 32); };
+            i32x8_t wq[AH + 1];
+#pragma unroll
+            for (int a = 0; a < AH; ++a) wq[a] = wfrag(a);
 #pragma unroll
             for (int st = 0; st < 2 * TN; ++st) {
                 const int s = st / TN, nt = st % TN;
-                i32x8_t wnext = wcur;
-                if (st + 1 < 2 * TN) wnext = frag(base + ((st + 1) / TN) * HALF_BYTES, wrow0 + ((st + 1) % TN) * 32);
-                if (st == TN - 1) {
+                if (st + AH < 2 * TN) wq[(st + AH) % (AH + 1)] = wfrag(st + AH);
+                if (st == (TN - 1 - AH >= 0 ? TN - 1 - AH : 0)) {      // the second image's X fragments, AH steps before their first use
 #pragma unroll
                     for (int mt = 0; mt < TM; ++mt) xa[1][mt] = frag(base + HALF_BYTES, xrow0 + mt * 32);
                 }
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wcur, xa[s][mt], acc[nt][mt], 0, 0, 0, kOne, 0, kOne);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[st % (AH + 1)], xa[s][mt], acc[nt][mt], 0, 0, 0, kOne, 0, kOne);
                 __builtin_amdgcn_sched_barrier(0);
-                wcur = wnext;
             }
             return;
         }

@@ -5,6 +5,7 @@
 block scales, twice the rate).  Interleaved rounds in one process, median (min..max) TFLOP/s per arm; the two fp8 forms are
 checked against each other first (same products, another summation order).
 usage: python tools/fp8_ab.py [nimg] [rounds]"""
+import os
 import statistics
 import sys
 from pathlib import Path
@@ -59,7 +60,8 @@ def main():
             hip.FP8_MX = 1 if form == 2 else 0
             xx, ww, al = (x, w, 1.0) if form == 0 else (x8, w8, sx * sw)
             hip.gemm(xx, ww, out, M=M, N=cout, K=c1, ldx=c1, ldw=ww.stride(0), ldc=cout, bias=bias, residual=res,
-                     ldr=cout if use_res else 0, mode=1 if conv else 0, Hin=H, Win=H, Hout=H, Wout=H, alpha=al)
+                     ldr=cout if use_res else 0, mode=1 if conv else 0, Hin=H, Win=H, Hout=H, Wout=H, alpha=al,
+                     tile=int(os.environ.get("SDV_AB_TILE", "0")))
         run(1)
         torch.cuda.synchronize()
         ref = out.float().clone()
