@@ -103,7 +103,7 @@ class _Res:
     def prepare_timesteps(self, emb: torch.Tensor):
         self.bias_table = hip.linear_small(emb, self.wt, self.bt, add=self.c1_bias, silu_in=True)
 
-    def _call_fp8(self, x, x2, nimg, H, W, step_ptr, circular):
+    def _call_fp8(self, x, x2, nimg, H, W, step_ptr, circular, out=None):
         HW = H * W
         gn = dict(nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True)
         # Activation scales: set by an explicit calibration run (UNetEngine.fp8_calibration - the pipeline runs a fixed pilot
@@ -122,14 +122,17 @@ class _Res:
         h8 = hip.groupnorm(h, self.g2, self.b2, fp8_scale=self.sx2, **gn)
         sc = hip.linear(x, self.ws, self.bs, x2=x2) if self.ws is not None else x
         return hip.conv3x3(h8, self.w2_8, self.c2_bias, nimg=nimg, H=H, W=W, residual=sc, circular=circular,
-                           alpha=self.sx2 * self.sw2)
+                           alpha=self.sx2 * self.sw2, out=out)
 
-    def __call__(self, x, x2, nimg, H, W, step_ptr, circular):
-        out = self._call_fp8(x, x2, nimg, H, W, step_ptr, circular) if self.fp8 else self._call_bf16(x, x2, nimg, H, W, step_ptr, circular)
+    def __call__(self, x, x2, nimg, H, W, step_ptr, circular, out=None):
+        """``out``: where the block's result goes (a row range of a larger tensor when the caller walks the batch in
+        cache-sized chunks of images, UNetEngine._segment)."""
+        call = self._call_fp8 if self.fp8 else self._call_bf16
+        out = call(x, x2, nimg, H, W, step_ptr, circular, out=out)
         _tap(self.name, "resnet", x=x, x2=x2, out=out, nimg=nimg, H=H, W=W)
         return out
 
-    def _call_bf16(self, x, x2, nimg, H, W, step_ptr, circular):
+    def _call_bf16(self, x, x2, nimg, H, W, step_ptr, circular, out=None):
         HW = H * W
         h = hip.groupnorm(x, self.g1, self.b1, nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True, x2=x2)
         if self.wt is not None:
@@ -143,7 +146,7 @@ class _Res:
         else:
             assert x2 is None
             sc = x
-        return hip.conv3x3(h, self.w2, self.c2_bias, nimg=nimg, H=H, W=W, residual=sc, circular=circular)
+        return hip.conv3x3(h, self.w2, self.c2_bias, nimg=nimg, H=H, W=W, residual=sc, circular=circular, out=out)
 
 
 class _Transformer:
@@ -208,12 +211,21 @@ class _Transformer:
         hip.gemm(self.wv2, ctx, ent[1], M=C, N=Lc, K=D, ldx=D, ldw=D, ldc=ldv, batch=nimg, sX=0, sW=Lc * D,
                  sC=C * ldv)
 
-    def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False):
-        out = self._forward(x, nimg, H, W, vt_ws, shared_prefix)
+    def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False, out=None, ctx_of=None):
+        """``out`` / ``ctx_of=(batch size the context was prepared for, first image)``: this call handles images
+        [first, first + nimg) of a larger batch and writes their rows of a larger tensor (UNetEngine._segment)."""
+        out = self._forward(x, nimg, H, W, vt_ws, shared_prefix, out, ctx_of)
         _tap(self.name, "transformer", x=x, out=out, nimg=nimg // 2 if shared_prefix else nimg, H=H, W=W, shared_prefix=shared_prefix)
         return out
 
-    def _forward(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False):
+    def _context(self, nimg, ctx_of):
+        if ctx_of is None:
+            return self.ctx[nimg]
+        total, first = ctx_of
+        ctx_k, ctx_vt, Lc = self.ctx[total]
+        return ctx_k[first * Lc:(first + nimg) * Lc], ctx_vt[first:first + nimg], Lc
+
+    def _forward(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False, out=None, ctx_of=None):
         """x: [nimg*HW, C] tokens.  With ``shared_prefix`` x holds only nimg/2 samples whose two CFG copies
         (unconditional / conditional) are still identical: everything up to the cross-attention - GroupNorm, proj_in,
         the whole self-attention, the cross-attention query - is computed ONCE, and the batch doubles where the
@@ -223,7 +235,7 @@ class _Transformer:
         Mb, M = nb * HW, nimg * HW
         scale = dh ** -0.5
         if not self.fold:
-            return self._call_unfolded(x, nimg, H, W, vt_ws, shared_prefix)
+            return self._call_unfolded(x, nimg, H, W, vt_ws, shared_prefix, out, ctx_of)
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
         h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)            # + (mean, rstd) of every token for norm1
         _tap(self.name, "tf_in", x=x, out=h, nimg=nb, H=H, W=W)
@@ -247,7 +259,7 @@ class _Transformer:
         # --- cross attention on the text context (LN2 inside the Q projection) ---
         q = hip.linear(h, self.wq2, self.tq2, alpha=qs, ln=(st2, self.sq2))
         o2 = torch.empty((M, C), dtype=BF16, device=x.device)
-        ctx_k, ctx_vt, Lc = self.ctx[nimg]
+        ctx_k, ctx_vt, Lc = self._context(nimg, ctx_of)
         if not shared_prefix:
             hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
                           ldo=C, scale=scale, q_prescaled=True)
@@ -269,16 +281,17 @@ class _Transformer:
         h = hip.linear(g, self.wff2, self.bff2, residual=h)
         _tap(self.name, "tf_ff", x=h_in, out=h, nimg=nimg, H=H, W=W)
         if not shared_prefix:
-            out = hip.linear(h, self.w_out, self.b_out, residual=x)
+            out = hip.linear(h, self.w_out, self.b_out, residual=x, out=out)
         else:
-            out = torch.empty((M, C), dtype=BF16, device=x.device)           # residual x is the shared (nb-sample) input
+            if out is None:
+                out = torch.empty((M, C), dtype=BF16, device=x.device)       # residual x is the shared (nb-sample) input
             hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
                      sX=Mb * C, sW=0, sC=Mb * C, sR=0)
         _tap(self.name, "tf_out", x=h, x2=x, out=out, nimg=nimg, H=H, W=W, shared_prefix=shared_prefix)
         return out
 
 
-    def _call_unfolded(self, x, nimg, H, W, vt_ws, shared_prefix):
+    def _call_unfolded(self, x, nimg, H, W, vt_ws, shared_prefix, out=None, ctx_of=None):
         """The same block with the three LayerNorms as stand-alone kernels (A/B reference for the fold, SDV_LN_FOLD=0)."""
         C, HW, heads, dh = self.C, H * W, self.heads, self.dh
         nb = nimg // 2 if shared_prefix else nimg
@@ -297,7 +310,7 @@ class _Transformer:
         n2 = hip.layernorm(h, *self.ln_plain[1])
         q = hip.linear(n2, self.p_wq2, alpha=qs)
         o2 = torch.empty((M, C), dtype=BF16, device=x.device)
-        ctx_k, ctx_vt, Lc = self.ctx[nimg]
+        ctx_k, ctx_vt, Lc = self._context(nimg, ctx_of)
         if not shared_prefix:
             hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
                           ldo=C, scale=scale, q_prescaled=True)
@@ -314,8 +327,9 @@ class _Transformer:
         g = hip.linear(n3, self.p_wff1, self.p_bff1, epi=1)
         h = hip.linear(g, self.wff2, self.bff2, residual=h)
         if not shared_prefix:
-            return hip.linear(h, self.w_out, self.b_out, residual=x)
-        out = torch.empty((M, C), dtype=BF16, device=x.device)
+            return hip.linear(h, self.w_out, self.b_out, residual=x, out=out)
+        if out is None:
+            out = torch.empty((M, C), dtype=BF16, device=x.device)
         hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
                  sX=Mb * C, sW=0, sC=Mb * C, sR=0)
         return out
@@ -453,6 +467,50 @@ class UNetEngine:
             if blk["up"] is not None:
                 h, w = 2 * h, 2 * w
 
+    # -- cache blocking ----------------------------------------------------------------------
+    # At 128 frames (256 samples) every activation of the 64 x 64 level is 671 MB: each kernel of a ResBlock / transformer
+    # block streams its input from HBM and its output back, ~37 passes per transformer block, and the K <= 640 GEMMs, the
+    # GroupNorm passes and the residual adds are bound by exactly those bytes (DESIGN (d)).  Every op of a block is local to
+    # one image, so the block can just as well run image chunk by image chunk: with a chunk's activation well under the
+    # 256 MiB Infinity Cache the producer's output is still on chip when its consumer reads it, and the chunk loop re-uses the
+    # same intermediate buffers.  Same kernels, same per-row arithmetic - only the launch order changes
+    # (tests/test_model_gpu.py::test_cache_blocked_forward).  The chunk is given in ROWS (tokens) so that every launch of a
+    # chunk covers a whole number of 256-workgroup rounds of the persistent 256-row tiles (65536 rows = one round).
+    chunk_rows = int(os.environ.get("SDV_CHUNK_ROWS", "0"))
+
+    def _chunk_images(self, HW: int, nimg: int) -> int:
+        """Images per chunk for a [nimg*HW, C] activation (0 = run the whole batch at once)."""
+        env = os.environ.get("SDV_CHUNK_ROWS")              # (read per call: tools/chunk_ab.py flips it between forwards)
+        rows = int(env) if env is not None else self.chunk_rows
+        levels = os.environ.get("SDV_CHUNK_LEVELS")         # optional: comma list of HW values the blocking applies to
+        if rows <= 0 or TAP is not None or (levels and str(HW) not in levels.split(",")):
+            return 0
+        n = max(1, rows // HW)
+        return n if nimg >= 2 * n else 0
+
+    def _segment(self, r: "_Res", t: Optional["_Transformer"], h, skip, nimg: int, nb: int, hh: int, ww: int, step_ptr, circ,
+                 first: bool = False):
+        """One ResBlock and the transformer block behind it (if any), cache-blocked over images when that pays."""
+        HW = hh * ww
+        n = 0 if first else self._chunk_images(HW, nimg)
+        if n == 0:
+            h = r(h, skip, nb if first else nimg, hh, ww, step_ptr, circ)
+            if t is not None:
+                h = t(h, nimg, hh, ww, self._vt(nimg, t.C, HW), shared_prefix=first)
+            return h
+        out = torch.empty((nimg * HW, r.cout), dtype=BF16, device=self.device)
+        vt = self._vt(nimg, t.C, HW) if t is not None else None
+        for lo in range(0, nimg, n):
+            m = min(n, nimg - lo)
+            rows = slice(lo * HW, (lo + m) * HW)
+            sk = skip[rows] if skip is not None else None
+            if t is None:
+                r(h[rows], sk, m, hh, ww, step_ptr, circ, out=out[rows])
+            else:
+                y = r(h[rows], sk, m, hh, ww, step_ptr, circ)
+                t(y, m, hh, ww, vt[:m], out=out[rows], ctx_of=(nimg, lo))
+        return out
+
     # -- one denoise forward -----------------------------------------------------------------
     def forward(self, x: torch.Tensor, nimg: int, H: int, W: int, step_ptr: torch.Tensor,
                 cfg_shared: bool = False) -> torch.Tensor:
@@ -480,10 +538,7 @@ class UNetEngine:
         for bi, blk in enumerate(self.down):
             for j, r in enumerate(blk["res"]):
                 first = shared and bi == 0 and j == 0
-                h = r(h, None, nb if first else nimg, hh, ww, step_ptr, circ)
-                if blk["attn"]:
-                    t = blk["attn"][j]
-                    h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww), shared_prefix=first)
+                h = self._segment(r, blk["attn"][j] if blk["attn"] else None, h, None, nimg, nb, hh, ww, step_ptr, circ, first)
                 skips.append(h)
             if blk["down"] is not None:
                 wd, bd = blk["down"]
@@ -498,10 +553,7 @@ class UNetEngine:
         h = r1(h, None, nimg, hh, ww, step_ptr, circ)
         for bi, blk in enumerate(self.up):
             for j, r in enumerate(blk["res"]):
-                h = r(h, skips.pop(), nimg, hh, ww, step_ptr, circ)
-                if blk["attn"]:
-                    t = blk["attn"][j]
-                    h = t(h, nimg, hh, ww, self._vt(nimg, t.C, hh * ww))
+                h = self._segment(r, blk["attn"][j] if blk["attn"] else None, h, skips.pop(), nimg, nb, hh, ww, step_ptr, circ)
             if blk["up"] is not None:
                 wu, bu = blk["up"]
                 h_in = h

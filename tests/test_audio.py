@@ -96,3 +96,25 @@ def test_librosa_version_choices_move_T_by_less_than_a_frame(monkeypatch):
     monkeypatch.setattr(audio, "load_audio", fft_load)
     other = get_timesteps_arr(str(WAV), offset=offset, duration=duration, fps=fps)
     assert np.abs(other - base).max() < 0.5 / n
+
+
+def test_stft_and_mel_stage_match_the_transformers_restatement_of_librosa():
+    """An independent pin for two of the unpinned stages: ``transformers.audio_utils`` (installed here, written to reproduce
+    ``librosa.stft`` / ``librosa.filters.mel`` / ``librosa.feature.melspectrogram`` for the Whisper / CLAP feature extractors)
+    must agree with the numpy restatement on the reference's own fixture - complex STFT, Slaney filter bank and the mel power
+    spectrogram of ``utils.py:25`` (n_fft 2048, hop 512, periodic hann, centred).  HPSS and the resampler stay unpinned."""
+    tau = pytest.importorskip("transformers.audio_utils")
+    y, sr = audio.load_audio(WAV, offset=1.0, duration=3.0)
+    fb = tau.mel_filter_bank(num_frequency_bins=1025, num_mel_filters=128, min_frequency=0.0, max_frequency=sr / 2,
+                             sampling_rate=sr, norm="slaney", mel_scale="slaney")
+    assert np.abs(fb.T - audio.mel_filterbank(sr)).max() < 1e-7 * np.abs(fb).max()
+    assert abs(float(tau.hertz_to_mel(4000.0, "slaney")) - float(audio._hz_to_mel(4000.0))) < 1e-9
+    win = tau.window_function(2048, "hann")
+    for pad in ("reflect", "constant"):                      # the two librosa-version-dependent paddings (audio.STFT_PAD_MODE)
+        S = tau.spectrogram(y, win, frame_length=2048, hop_length=512, fft_length=2048, power=None, center=True, pad_mode=pad)
+        D = audio.stft(y, pad_mode=pad)
+        assert S.shape == D.shape and np.abs(S - D).max() < 1e-6 * np.abs(S).max()
+        mel = tau.spectrogram(y, win, frame_length=2048, hop_length=512, fft_length=2048, power=2.0, center=True, pad_mode=pad,
+                              mel_filters=fb, mel_floor=0.0)
+        mine = audio.mel_filterbank(sr) @ (np.abs(D) ** 2)
+        assert np.abs(mel - mine).max() < 1e-6 * np.abs(mel).max()

@@ -534,6 +534,52 @@ def test_cfg_shared_prefix_is_exact(hip, dev):
         assert float((a[:2] - a[2:]).abs().max()) > 1e-3      # the two halves really differ (different text context)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_cache_blocked_forward(hip, dev, fp8, monkeypatch):
+    """UNetEngine._segment walks a ResBlock (+ transformer) over the batch in cache-sized chunks of images.  Every op of those
+    blocks is local to one image, so the chunked forward must reproduce the whole-batch forward - same kernels, same per-row
+    arithmetic; only the row statistics behind the folded LayerNorms may be summed over differently shaped tiles.  Different
+    latents AND different contexts per image, ragged last chunk (5 images in chunks of 2), with and without the shared CFG prefix."""
+    from stable_diffusion_videos_amd import config as cfgs
+    for c in (cfgs.tiny_unet(), cfgs.sd14_unet()):
+        name = "sd14" if c.cross_attention_dim == 768 else "tiny"
+        if fp8 and name == "tiny":
+            continue
+        _, engine = unet_pair(c, dev, seed=4, fp8=fp8)
+        for nimg, shared in ((5, False), (6, True)):
+            g = torch.Generator().manual_seed(9 + nimg)
+            x = bf16_round(torch.randn((nimg, c.in_channels, 16, 16), generator=g))
+            if shared:
+                x = torch.cat([x[: nimg // 2]] * 2)
+            ctx = bf16_round(torch.randn((nimg, 77, c.cross_attention_dim), generator=g))
+            engine.prepare_timesteps([981, 961])
+            engine.prepare_context(ctx.to(dev))
+            step = torch.tensor([1], dtype=torch.int32, device=dev)
+            x2 = x.permute(0, 2, 3, 1).reshape(-1, c.in_channels).to(dev, BF16).contiguous()
+            monkeypatch.setenv("SDV_CHUNK_ROWS", "0")
+            if fp8:
+                engine.forward(x2, nimg, 16, 16, step, cfg_shared=shared)       # (the first eager forward calibrates the scales)
+            a = engine.forward(x2, nimg, 16, 16, step, cfg_shared=shared)
+            # chunk = 2 images of the 16 x 16 level (the smaller levels would take more images per chunk: they stay whole)
+            monkeypatch.setenv("SDV_CHUNK_ROWS", "512")
+            assert engine._chunk_images(256, nimg) == 2 and engine._chunk_images(64, nimg) == 0
+            launches = []
+            hip.LAUNCH_HOOK = lambda kind, info, fn: (launches.append(kind), fn())
+            b = engine.forward(x2, nimg, 16, 16, step, cfg_shared=shared)
+            hip.LAUNCH_HOOK = None
+            launches_b = len(launches)
+            monkeypatch.setenv("SDV_CHUNK_ROWS", "0")
+            hip.LAUNCH_HOOK = lambda kind, info, fn: (launches.append(kind), fn())
+            engine.forward(x2, nimg, 16, 16, step, cfg_shared=shared)
+            hip.LAUNCH_HOOK = None
+            torch.cuda.synchronize()
+            d = float((a - b).abs().max()) / float(a.abs().max())
+            report(f"cache-blocked vs whole-batch forward ({name}, fp8={fp8}, nimg={nimg}, shared={shared}): max |d eps| / max |eps| "
+                   f"= {d:.3e}, bit-identical: {torch.equal(a, b)}, launches {len(launches) - launches_b} -> {launches_b}")
+            assert launches_b > len(launches) - launches_b          # the chunk loop really ran
+            assert d <= 2e-3
+
+
 def _run_ranks(world, backend, args, extra_env=None, timeout=600):
     """Launch ``world`` ranks of tests/dist_walk_worker.py (all on cuda:0) and wait for them."""
     import os

@@ -291,3 +291,72 @@ def test_committed_block_vectors_are_what_the_generator_produces():
     z = np.load(GOLDEN / "blocks_f64.npz")
     assert set(fx) == set(z.files)
     assert all(np.array_equal(fx[k], z[k]) for k in fx)
+
+
+def _ldm_to_diffusers_decoder_keys(ldm_sd, n_levels):
+    """The published checkpoint conversion (diffusers ``convert_ldm_vae_checkpoint``): the SD VAE was trained with the CompVis
+    ``ldm`` Decoder and its weights reach ``AutoencoderKL.decoder`` through exactly this renaming - 1x1 attention convs become
+    Linear layers, ``nin_shortcut`` -> ``conv_shortcut``, ``norm_out`` -> ``conv_norm_out``, ``mid.block_k`` ->
+    ``mid_block.resnets.k-1``, ``up`` levels in processing order -> ``up_blocks``."""
+    out = {}
+    for k, v in ldm_sd.items():
+        k = k.replace("nin_shortcut", "conv_shortcut")
+        if k.startswith("mid.block_"):
+            k = k.replace("mid.block_1", "mid_block.resnets.0").replace("mid.block_2", "mid_block.resnets.1")
+        elif k.startswith("mid.attn_1."):
+            k = (k.replace("mid.attn_1.norm", "mid_block.attentions.0.group_norm")
+                  .replace("mid.attn_1.q", "mid_block.attentions.0.to_q").replace("mid.attn_1.k", "mid_block.attentions.0.to_k")
+                  .replace("mid.attn_1.v", "mid_block.attentions.0.to_v")
+                  .replace("mid.attn_1.proj_out", "mid_block.attentions.0.to_out.0"))
+            if v.ndim == 4:
+                v = v[:, :, 0, 0]
+        elif k.startswith("up."):
+            _, lvl, kind, rest = k.split(".", 3)
+            k = (f"up_blocks.{lvl}.resnets.{rest}" if kind == "block" else f"up_blocks.{lvl}.upsamplers.0.{rest}")
+        elif k.startswith("norm_out."):
+            k = "conv_" + k
+        out[k] = v
+    return out
+
+
+def test_vae_decoder_pinned_against_the_ldm_decoder_in_transformers():
+    """A THIRD-PARTY pin for row a15 ([3P] ``AutoencoderKL.decode``): ``transformers`` ships the CompVis ``ldm`` Decoder the SD
+    VAE was trained with (``JanusVQVAEDecoder``: GroupNorm(32, eps 1e-6) - swish - conv ResnetBlocks with ``nin_shortcut``,
+    single-head ``AttnBlock`` over 1x1 convs scaled by C^-0.5, nearest-2x + conv up-samplers, three ResnetBlocks per level,
+    ``norm_out`` - swish - ``conv_out``).  Built at the SD-VAE sizes (128 x (1, 2, 4, 4), 2 + 1 blocks per level, 4 latent
+    channels; its extra lowest-level attention blocks - ``attn_resolutions`` is empty in the SD config - are removed) with random
+    weights, and carried into the oracle through the published ldm -> diffusers key conversion, it must produce the oracle's output.
+    What stays unpinned: that diffusers executes those converted weights the way ldm did (its conversion script says so)."""
+    mj = pytest.importorskip("transformers.models.janus.modeling_janus")
+    from transformers.models.janus.configuration_janus import JanusVQVAEConfig
+    from oracle import models
+    cfg = models.sd_vae_config()
+    torch.manual_seed(11)
+    jc = JanusVQVAEConfig(base_channels=cfg.block_out_channels[0], channel_multiplier=[c // cfg.block_out_channels[0] for c in cfg.block_out_channels],
+                          num_res_blocks=cfg.layers_per_block, latent_channels=cfg.latent_channels, out_channels=cfg.out_channels, dropout=0.0)
+    ldm = mj.JanusVQVAEDecoder(jc).eval()
+    for up in ldm.up:
+        up.attn = torch.nn.ModuleList()                      # SD: attn_resolutions = [] (attention in the mid block only)
+    with torch.no_grad():
+        for n, p in ldm.named_parameters():                  # non-trivial norm scales / shifts and biases everywhere
+            p.copy_(torch.randn(p.shape) * (0.05 if p.ndim > 1 else 0.3))
+            if "norm" in n and n.endswith("weight"):
+                p.add_(1.0)
+    ours = models.Decoder(cfg).eval()
+    sd = _ldm_to_diffusers_decoder_keys(ldm.state_dict(), len(cfg.block_out_channels))
+    ours.load_state_dict(sd, strict=True)                    # every key of either side has its partner
+    assert models.count_params(ours) == sum(p.numel() for p in ldm.parameters())
+    z = torch.randn(2, cfg.latent_channels, 8, 8)
+    with torch.no_grad():
+        a = ldm(z.clone())
+        b = ours(z)
+    assert a.shape == b.shape == (2, 3, 64, 64)
+    rel = float((a - b).norm() / a.norm())
+    assert rel < 2e-5, rel
+    # the blocks one by one as well (the mid attention is where a scale / head-count slip would hide behind the ResBlocks)
+    x = torch.randn(2, 512, 8, 8)
+    with torch.no_grad():
+        assert float((ldm.mid.attn_1(x.clone()) - ours.mid_block.attentions[0](x)).abs().max()) < 1e-4
+        assert float((ldm.up[1].upsample(x.clone()) - ours.up_blocks[1].upsamplers[0](x)).abs().max()) < 1e-4
+        x2 = torch.randn(2, 512, 8, 8)
+        assert float((ldm.up[2].block[0](x2.clone()) - ours.up_blocks[2].resnets[0](x2)).abs().max()) < 1e-4   # 512 -> 256, nin_shortcut
