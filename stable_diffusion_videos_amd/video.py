@@ -3,17 +3,21 @@
 AAC audio track).  SURVEY.md section 8(f) rank 2.
 
 torchvision / pyav / ffmpeg are not installed in this image.  When they are, the reference encoding is used.  When
-they are not, a dependency-free writer produces a standards-conforming ISO-BMFF (.mp4) file with a Motion-JPEG
-video track (sample entry ``mp4v``, MPEG-4 objectTypeIndication 0x6C = JPEG, quality 95) and, when an audio file is
-given, an uncompressed 16-bit PCM audio track of the same ``[audio_offset, audio_offset + audio_duration)`` window
-(sample entry ``ipcm`` + ``pcmC``, ISO/IEC 23003-5) so that ``walk()`` returns the same ``{name}.mp4`` paths as the
-reference and the music video still carries its music; H.264 / AAC COMPRESSION needs ffmpeg and is what that mode
-lacks.  Frames are read once each (the reference's pairwise ``torch.cat`` is O(n^2), :91-93).
+they are not, a dependency-free writer produces a standards-conforming ISO-BMFF (.mp4) file with
+  * an **H.264 yuv420p video track** (sample entry ``avc1`` + ``avcC``; h264.py: every picture an IDR picture of I_PCM
+    macroblocks - lossless where libx264 crf 10 is near-lossless, uncompressed where libx264 compresses), or with
+    ``SDV_VIDEO_CODEC=mjpeg`` a Motion-JPEG track (sample entry ``mp4v``, objectTypeIndication 0x6C, quality 95), and
+  * when an audio file is given, an uncompressed 16-bit PCM audio track of the same ``[audio_offset, audio_offset +
+    audio_duration)`` window (sample entry ``ipcm`` + ``pcmC``, ISO/IEC 23003-5) where the reference has AAC,
+so that ``walk()`` returns the same ``{name}.mp4`` paths as the reference, in the reference's video codec and pixel format, and
+the music video still carries its music; entropy-coded H.264 and AAC need ffmpeg and are what this mode lacks.  Frames are
+read once each (the reference's pairwise ``torch.cat`` is O(n^2), :91-93).
 """
 from __future__ import annotations
 
 import io
 import logging
+import os
 import struct
 from pathlib import Path
 from typing import List, Optional, Union
@@ -22,6 +26,10 @@ import numpy as np
 import torch
 
 logger = logging.getLogger("stable_diffusion_videos_amd")
+
+# Codec of the dependency-free writer (env SDV_VIDEO_CODEC overrides): "h264" = the reference's codec family, lossless intra
+# pictures (h264.py, 1.5 bytes per pixel); "mjpeg" = JPEG quality 95 frames (~3x smaller, not playable in browsers).
+DEFAULT_CODEC = "h264"
 
 
 def _box(kind: bytes, payload: bytes) -> bytes:
@@ -35,6 +43,87 @@ def _full(kind: bytes, version: int, flags: int, payload: bytes) -> bytes:
 def _descr(tag: int, payload: bytes) -> bytes:
     assert len(payload) < 128
     return bytes([tag, len(payload)]) + payload
+
+
+def _pcm_audio_trak(n_audio: int, sr: int, a_duration: int, chunk_offset: int, matrix: bytes, dinf: bytes) -> bytes:
+    """Track 2: ONE chunk of ``n_audio`` mono 16-bit little-endian PCM samples at ``chunk_offset`` (``ipcm`` + ``pcmC``)."""
+    a_tkhd = _full(b"tkhd", 0, 3, struct.pack(">IIIII", 0, 0, 2, 0, a_duration) + b"\0" * 8 +
+                   struct.pack(">HHHH", 0, 0, 0x0100, 0) + matrix + struct.pack(">II", 0, 0))
+    a_mdhd = _full(b"mdhd", 0, 0, struct.pack(">IIII", 0, 0, int(sr), n_audio) + struct.pack(">HH", 0x55C4, 0))
+    a_hdlr = _full(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"soun") + b"\0" * 12 + b"SoundHandler\0")
+    smhd = _full(b"smhd", 0, 0, struct.pack(">HH", 0, 0))
+    pcmc = _full(b"pcmC", 0, 0, bytes([1, 16]))                       # format_flags 1 = little endian, 16 bits per sample
+    chnl = _full(b"chnl", 0, 0, bytes([1, 1]) + struct.pack(">Q", 0))  # channel-structured, defined layout 1 = mono
+    ipcm = _box(b"ipcm", b"\0" * 6 + struct.pack(">H", 1) + b"\0" * 8 + struct.pack(">HHHH", 1, 16, 0, 0) +
+                struct.pack(">I", (int(sr) & 0xFFFF) << 16) + pcmc + chnl)
+    a_stsd = _full(b"stsd", 0, 0, struct.pack(">I", 1) + ipcm)
+    a_stts = _full(b"stts", 0, 0, struct.pack(">III", 1, n_audio, 1))
+    a_stsc = _full(b"stsc", 0, 0, struct.pack(">IIII", 1, 1, n_audio, 1))
+    a_stsz = _full(b"stsz", 0, 0, struct.pack(">II", 2, n_audio))
+    a_stco = (_full(b"stco", 0, 0, struct.pack(">II", 1, chunk_offset)) if chunk_offset < (1 << 32) else
+              _full(b"co64", 0, 0, struct.pack(">IQ", 1, chunk_offset)))
+    a_stbl = _box(b"stbl", a_stsd + a_stts + a_stsc + a_stsz + a_stco)
+    return _box(b"trak", a_tkhd + _box(b"mdia", a_mdhd + a_hdlr + _box(b"minf", smhd + dinf + a_stbl)))
+
+
+def _pcm16(audio, sr):
+    if audio is None or not len(audio):
+        return b"", 0
+    a16 = np.clip(np.round(np.asarray(audio, dtype=np.float64).reshape(-1) * 32767.0), -32768, 32767).astype("<i2")
+    return a16.tobytes(), int(a16.shape[0])
+
+
+def write_h264_mp4(frames, width: int, height: int, fps: float, path: Union[str, Path],
+                   audio: Optional[np.ndarray] = None, sr: int = 44100) -> str:
+    """ISO base media file with an H.264 video track (sample entry ``avc1`` + ``avcC``; every sample one IDR picture of I_PCM
+    macroblocks, h264.py) and the optional PCM audio track: ftyp | mdat (64-bit size; length-prefixed NAL units streamed to disk
+    frame by frame, then the PCM samples) | moov.  ``frames``: iterable of uint8 RGB [H, W, 3]."""
+    from . import h264
+    timescale = 90000
+    delta = int(round(timescale / float(fps)))
+    sps, pps = h264.sps_pps(width, height, fps)
+    pcm, n_audio = _pcm16(audio, sr)
+    ftyp = _box(b"ftyp", b"isom" + struct.pack(">I", 0x200) + b"isomiso2avc1mp41")
+    data_offset = len(ftyp) + 16
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    sizes = []
+    with open(path, "wb") as f:
+        f.write(ftyp + struct.pack(">I4sQ", 1, b"mdat", 0))            # largesize patched below
+        for k, fr in enumerate(frames):
+            assert fr.shape[:2] == (height, width), "all frames of a video have one size"
+            nal = h264.idr_picture(np.ascontiguousarray(fr[..., :3]), k)
+            f.write(struct.pack(">I", len(nal)) + nal)
+            sizes.append(4 + len(nal))
+        n, video_bytes = len(sizes), sum(sizes)
+        f.write(pcm)
+        duration = n * delta
+        a_duration = int(round(n_audio * timescale / float(sr))) if n_audio else 0
+        matrix = struct.pack(">9I", 0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000)
+        mvhd = _full(b"mvhd", 0, 0, struct.pack(">IIII", 0, 0, timescale, max(duration, a_duration)) + struct.pack(">IH", 0x10000, 0x100) +
+                     b"\0" * 10 + matrix + b"\0" * 24 + struct.pack(">I", 3 if n_audio else 2))
+        dinf = _box(b"dinf", _full(b"dref", 0, 0, struct.pack(">I", 1) + _full(b"url ", 0, 1, b"")))
+        tkhd = _full(b"tkhd", 0, 3, struct.pack(">IIIII", 0, 0, 1, 0, duration) + b"\0" * 8 + struct.pack(">HHHH", 0, 0, 0, 0) +
+                     matrix + struct.pack(">II", width << 16, height << 16))
+        mdhd = _full(b"mdhd", 0, 0, struct.pack(">IIII", 0, 0, timescale, duration) + struct.pack(">HH", 0x55C4, 0))
+        hdlr = _full(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"vide") + b"\0" * 12 + b"VideoHandler\0")
+        vmhd = _full(b"vmhd", 0, 1, struct.pack(">HHHH", 0, 0, 0, 0))
+        avc1 = _box(b"avc1", b"\0" * 6 + struct.pack(">H", 1) + b"\0" * 16 + struct.pack(">HH", width, height) +
+                    struct.pack(">II", 0x480000, 0x480000) + struct.pack(">I", 0) + struct.pack(">H", 1) + b"\0" * 32 +
+                    struct.pack(">Hh", 0x18, -1) + _box(b"avcC", h264.avcc_box_payload(sps, pps)))
+        stsd = _full(b"stsd", 0, 0, struct.pack(">I", 1) + avc1)
+        stts = _full(b"stts", 0, 0, struct.pack(">III", 1, n, delta))
+        stsc = _full(b"stsc", 0, 0, struct.pack(">IIII", 1, 1, n, 1))
+        stsz = _full(b"stsz", 0, 0, struct.pack(">II", 0, n) + struct.pack(f">{n}I", *sizes))
+        stco = _full(b"stco", 0, 0, struct.pack(">II", 1, data_offset))
+        # no stss box: every sample is a sync sample (all pictures are IDR pictures)
+        stbl = _box(b"stbl", stsd + stts + stsc + stsz + stco)
+        traks = _box(b"trak", tkhd + _box(b"mdia", mdhd + hdlr + _box(b"minf", vmhd + dinf + stbl)))
+        if n_audio:
+            traks += _pcm_audio_trak(n_audio, sr, a_duration, data_offset + video_bytes, matrix, dinf)
+        f.write(_box(b"moov", mvhd + traks))
+        f.seek(len(ftyp) + 8)
+        f.write(struct.pack(">Q", 16 + video_bytes + len(pcm)))
+    return str(path)
 
 
 def write_mjpeg_mp4(jpegs: List[bytes], width: int, height: int, fps: float, path: Union[str, Path],
@@ -83,24 +172,8 @@ def write_mjpeg_mp4(jpegs: List[bytes], width: int, height: int, fps: float, pat
     minf = _box(b"minf", vmhd + dinf + stbl)
     traks = _box(b"trak", tkhd + _box(b"mdia", mdhd + hdlr + minf))
 
-    # ---- audio track: one chunk of n_audio two-byte samples behind the video samples ----
     if n_audio:
-        a_tkhd = _full(b"tkhd", 0, 3, struct.pack(">IIIII", 0, 0, 2, 0, a_duration) + b"\0" * 8 +
-                       struct.pack(">HHHH", 0, 0, 0x0100, 0) + matrix + struct.pack(">II", 0, 0))
-        a_mdhd = _full(b"mdhd", 0, 0, struct.pack(">IIII", 0, 0, int(sr), n_audio) + struct.pack(">HH", 0x55C4, 0))
-        a_hdlr = _full(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"soun") + b"\0" * 12 + b"SoundHandler\0")
-        smhd = _full(b"smhd", 0, 0, struct.pack(">HH", 0, 0))
-        pcmc = _full(b"pcmC", 0, 0, bytes([1, 16]))                       # format_flags 1 = little endian, 16 bits per sample
-        chnl = _full(b"chnl", 0, 0, bytes([1, 1]) + struct.pack(">Q", 0))  # channel-structured, defined layout 1 = mono
-        ipcm = _box(b"ipcm", b"\0" * 6 + struct.pack(">H", 1) + b"\0" * 8 + struct.pack(">HHHH", 1, 16, 0, 0) +
-                    struct.pack(">I", (int(sr) & 0xFFFF) << 16) + pcmc + chnl)
-        a_stsd = _full(b"stsd", 0, 0, struct.pack(">I", 1) + ipcm)
-        a_stts = _full(b"stts", 0, 0, struct.pack(">III", 1, n_audio, 1))
-        a_stsc = _full(b"stsc", 0, 0, struct.pack(">IIII", 1, 1, n_audio, 1))
-        a_stsz = _full(b"stsz", 0, 0, struct.pack(">II", 2, n_audio))
-        a_stco = _full(b"stco", 0, 0, struct.pack(">II", 1, data_offset + len(video_bytes)))
-        a_stbl = _box(b"stbl", a_stsd + a_stts + a_stsc + a_stsz + a_stco)
-        traks += _box(b"trak", a_tkhd + _box(b"mdia", a_mdhd + a_hdlr + _box(b"minf", smhd + dinf + a_stbl)))
+        traks += _pcm_audio_trak(n_audio, sr, a_duration, data_offset + len(video_bytes), matrix, dinf)
     moov = _box(b"moov", mvhd + traks)
     Path(path).parent.mkdir(parents=True, exist_ok=True)
     with open(path, "wb") as f:
@@ -141,16 +214,24 @@ def make_video_pyav(frames_or_frame_dir: Union[str, Path, torch.Tensor] = "./ima
         else:
             write_video(output_filepath, stack, fps=fps, options={"crf": "10", "pix_fmt": "yuv420p"})
         return output_filepath
-    from PIL import Image
     audio = None
+    codec = (os.environ.get("SDV_VIDEO_CODEC") or DEFAULT_CODEC).lower()
+    if codec not in ("h264", "mjpeg"):
+        raise ValueError(f"SDV_VIDEO_CODEC={codec!r}: expected 'h264' or 'mjpeg'")
+    h, w = frames[0].shape[:2]
+    if codec == "h264" and (h % 2 or w % 2):
+        logger.warning("odd frame size %dx%d: yuv420p needs even sizes, writing Motion-JPEG instead", w, h)
+        codec = "mjpeg"
     if audio_filepath:
         from .audio import load_audio
-        logger.warning("no ffmpeg/pyav in this environment: writing a Motion-JPEG mp4 with an uncompressed PCM audio track")
+        logger.warning("no ffmpeg/pyav in this environment: the audio track is uncompressed 16-bit PCM instead of AAC")
         audio, _ = load_audio(audio_filepath, sr=sr, mono=True, offset=audio_offset, duration=audio_duration)
+    if codec == "h264":
+        return write_h264_mp4(frames, w, h, fps, output_filepath, audio=audio, sr=sr)
+    from PIL import Image
     jpegs = []
     for fr in frames:
         buf = io.BytesIO()
         Image.fromarray(fr).save(buf, format="JPEG", quality=95, subsampling=2)
         jpegs.append(buf.getvalue())
-    h, w = frames[0].shape[:2]
     return write_mjpeg_mp4(jpegs, w, h, fps, output_filepath, audio=audio, sr=sr)
