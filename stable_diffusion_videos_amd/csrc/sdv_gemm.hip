@@ -26,6 +26,12 @@
 
 #include "sdv_common.h"
 
+// W fragments in flight ahead of the MFMAs in the bf16 K loop of the big (kPipeFrags) tiles; 0 = the round-2 order (two whole
+// fragment sets, compiler-scheduled) - kept for A/B builds (tools/ubench/build_whatif.py style: -DSDV_BF16_ROT_AH=0).
+#ifndef SDV_BF16_ROT_AH
+#define SDV_BF16_ROT_AH 2
+#endif
+
 namespace {
 
 // waves per SIMD the register allocator must leave room for: the 32-wide-K tiles are meant to run two workgroups
@@ -432,6 +438,39 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 #pragma unroll
                     for (int mt = 0; mt < TM; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[nt], xs[mt], acc[nt][mt], 0, 0, 0);
+            }
+            return;
+        }
+        if constexpr (SDV_BF16_ROT_AH > 0) {
+            // Rotating W fragments (the MX order above, for the bf16 tiles): a step = ONE W fragment against the TM X fragments of
+            // its k-step.  Live fragment registers: X of this k-step and - from AH steps before its first use - of the next one
+            // (2 x TM x 4), one W fragment in use and AH in flight behind the TM MFMAs of each step ((AH + 1) x 4): 28 registers
+            // at AH = 2 where two whole fragment sets took 56.  With those the compiler had run out of registers in the last
+            // k-steps of a slab and fallen back to read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per W fragment, the LDS latency of every
+            // read exposed (ISA of round 3); here the issue order is pinned by the sched_barriers and every read has AH x TM MFMAs
+            // (64 matrix-pipe cycles each pair) to land.  Same accumulation order per output tile: bit-identical results.
+            constexpr int AH = SDV_BF16_ROT_AH, STEPS = KSTEPS * TN;
+            bf16x8_t xa[2][TM], wq[AH + 1];
+            auto wfrag = [&](int st) __attribute__((always_inline)) {
+                return *(const bf16x8_t*)(base + (wrow0 + (st % TN) * 32) * ROWB + frag_off[st / TN]);
+            };
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) xa[0][mt] = *(const bf16x8_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[0]);
+#pragma unroll
+            for (int a = 0; a < AH; ++a) wq[a] = wfrag(a);
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int ks = st / TN, nt = st % TN;
+                if (st + AH < STEPS) wq[(st + AH) % (AH + 1)] = wfrag(st + AH);
+                if (nt == (TN - 1 - AH >= 0 ? TN - 1 - AH : 0) && ks + 1 < KSTEPS) {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+                        xa[(ks + 1) & 1][mt] = *(const bf16x8_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[ks + 1]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[st % (AH + 1)], xa[ks & 1][mt], acc[nt][mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             return;
         }
