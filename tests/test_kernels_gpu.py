@@ -640,7 +640,14 @@ def test_layernorm(hip, dev, C):
 # interpolation, CFG + DDIM, embeddings
 # ------------------------------------------------------------------------------------------------
 def test_slerp_matches_reference_golden(hip, dev):
-    """HIP slerp vs the vectors produced by the reference's own slerp (tests/golden/make_golden.py)."""
+    """HIP slerp vs the vectors produced by the reference's own slerp (tests/golden/make_golden.py).
+
+    Not bit-exact by construction, and the bound says by how much: the reference reduces ``dot`` and evaluates arccos / sin in
+    float32 numpy scalars (utils.py:51-59; pairwise fp32 sums over 16384 elements move ``dot`` by ~1e-7), the kernel reduces and
+    evaluates the two coefficients in fp64 and rounds them to fp32 ONCE, then forms ``s0 * v0 + s1 * v1`` with one fused
+    multiply-add where numpy rounds both products.  Emulating exactly that arithmetic on the CPU against the golden vectors gives
+    max |d| = 4.8e-7 = 1 ulp of the largest element (4.22) on the seeded pair, 2.4e-7 / 1.2e-7 on the (anti)parallel pairs; the
+    gate is 2 ulp of the largest element of each golden frame (~9.5e-7; it was a flat 2e-5 = 40 ulp in round 2)."""
     for name in ("slerp_seed42_1337_fp32", "slerp_parallel_fp32", "slerp_antiparallel_fp32"):
         d = np.load(GOLDEN / f"{name}.npz")
         v0, v1 = torch.from_numpy(d["v0"]).to(dev), torch.from_numpy(d["v1"]).to(dev)
@@ -650,13 +657,15 @@ def test_slerp_matches_reference_golden(hip, dev):
         out = hip.slerp_batch(v0, v1, stats, T, C_=1, HW=v0.numel(), to_hwc=False)
         for i, t in enumerate(ts):
             gold = torch.from_numpy(d[f"t{int(t * 100):03d}"]).to(dev).flatten()
-            assert float((out[i] - gold).abs().max()) < 2e-5, (name, t)
+            tol = 2.0 * float(np.spacing(np.float32(gold.abs().max().item())))
+            err = float((out[i] - gold).abs().max())
+            assert err <= tol, (name, t, err, tol)
     # NHWC output layout + public slerp() helper
     from stable_diffusion_videos_amd.utils import slerp
     d = np.load(GOLDEN / "slerp_seed42_1337_fp32.npz")
     v0, v1 = torch.from_numpy(d["v0"]).to(dev), torch.from_numpy(d["v1"]).to(dev)
     got = slerp(0.5, v0, v1)
-    assert got.shape == v0.shape and float((got.cpu() - torch.from_numpy(d["t050"])).abs().max()) < 2e-5
+    assert got.shape == v0.shape and float((got.cpu() - torch.from_numpy(d["t050"])).abs().max()) <= 2.0 * float(np.spacing(np.float32(np.abs(d["t050"]).max())))
     stats = hip.slerp_stats(v0, v1)
     hwc = hip.slerp_batch(v0, v1, stats, torch.tensor([0.5], device=dev), C_=4, HW=64 * 64, to_hwc=True)
     assert torch.allclose(hwc.view(64, 64, 4).permute(2, 0, 1), got[0], atol=1e-6)
