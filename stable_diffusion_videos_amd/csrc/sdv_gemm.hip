@@ -27,7 +27,7 @@
 #include "sdv_common.h"
 
 // W fragments in flight ahead of the MFMAs in the bf16 K loop of the big (kPipeFrags) tiles; 0 = the round-2 order (two whole
-// fragment sets, compiler-scheduled) - kept for A/B builds (tools/ubench/build_whatif.py style: -DSDV_BF16_ROT_AH=0).
+// fragment sets, compiler-scheduled) - kept for A/B builds (tools/ubench/build_variant.py ah0 -DSDV_BF16_ROT_AH=0).
 #ifndef SDV_BF16_ROT_AH
 #define SDV_BF16_ROT_AH 2
 #endif
