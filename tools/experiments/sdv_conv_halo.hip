@@ -1,0 +1,275 @@
+// conv3x3 (stride 1, pad 1, NHWC bf16) with the input window staged ONCE per channel slab - the "halo tile" form of the
+// implicit GEMM in sdv_gemm.hip, for the ResBlock convolutions of UNet2DConditionModel / AutoencoderKL
+// (reference: unet(...) stable_diffusion_pipeline.py:418, vae.decode :433).
+//
+// Why a second conv kernel: DESIGN.md (d) "Staged bytes per FLOP" - the igemm tiles run near the CU's LDS-fill
+// rate (18-20 B/clk/CU for cache-resident operands), and the tap-major implicit GEMM stages (256 + 320) x 64 x 2 B for EVERY
+// (tap, 64-channel slab): 663 KB per channel slab of a 256 x 320 tile, 295 KB of it the same pixels nine times.  Here the
+// (rows + 2) x (W + 2) pixel window of the tile's 256 output pixels is staged once per channel slab (<= 400 halo pixels x 128 B =
+// 51 KB; image borders and the padding columns are zero-filled by the buffer range check) and the nine taps read their X
+// fragments from it at shifted rows; only the nine 40 KB W slabs stream, double-buffered: 411 KB per channel slab, 1.6x fewer
+// staged bytes per FLOP.
+//
+// Tile: 256 output pixels (whole image rows; several whole images when H*W < 256) x 320 output channels, 8 waves = 4 (pixels) x 2
+// (channels), wave tile 64 x 160 = TM 2 x TN 5 accumulators of v_mfma_f32_32x32x16_bf16 (A = W rows, B = pixels - the layout of
+// the igemm, so the results differ from it only by the order the (channel slab, tap) partial sums are accumulated in).
+// LDS rows are 128 B (64 channels) with the igemm's XOR swizzle: position (row, chunk') holds channel chunk chunk' ^ ((row >> 1) & 7).
+#include "sdv_common.h"
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int kRecords = 0x7ffffff0;
+constexpr int BM = 256, BN = 320, ROWB = 128, KSTEPS = 4, TM = 2, TN = 5;
+constexpr int NXP = 7, NWP = 5;                   // LDS-DMA pieces (1 KB = 8 rows) per wave: X window (56 >= 50), W slab (40)
+constexpr int XROWS = 8 * 8 * NXP;                // 448 rows staged (the layouts use <= 400; surplus pieces read zeros)
+constexpr int X_BYTES = XROWS * ROWB;             // 57344
+constexpr int W_BYTES = BN * ROWB;                // 40960
+constexpr int LDS_BYTES = X_BYTES + 2 * W_BYTES;  // 139264
+
+struct HaloArgs {
+    const uint16_t* X;
+    const uint16_t* X2;     // second source of a channel concat (up blocks), or null
+    const uint16_t* W;      // [Cout][9 * (C1 + C2)], OHWI: column = tap * K + channel, tap = ky * 3 + kx
+    const float* bias;      // [Cout] (already offset by the step table row)
+    const uint16_t* R;      // residual [M][ldr] or null
+    uint16_t* C;            // [M][ldc]
+    int nimg, H, Wd, C1, C2, Cout, ldx, ldx2, ldw, ldr, ldc;
+};
+
+__device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
+
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsX = smem;
+    char* const ldsW = smem + X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int K = p.C1 + p.C2;
+    const int tiles_n = p.Cout / BN;
+    const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int Wd = p.Wd, H = p.H, HW = H * Wd;
+    const long long M = (long long)p.nimg * HW;
+
+    // ---- tile geometry: SEG whole images of RS rows each (SEG = 1: RS consecutive rows of one image) ----
+    const int SEG = HW >= BM ? 1 : BM / HW;
+    const int RS = HW >= BM ? BM / Wd : H;
+    const int PW = Wd + 2;
+    const int SEGSZ = (RS + 2) * PW;
+    const int SEGPX = RS * Wd;                       // output pixels per segment
+    const int img0 = m0 / HW;
+    const int y0 = (m0 - img0 * HW) / Wd;            // first image row of the tile (0 when SEG > 1)
+
+    // ---- staging addresses (tile-invariant over the K loop) ----
+    // X window piece g = wave + 8 i covers halo rows g*8 .. g*8+7; lane -> (row g*8 + lane/8, LDS chunk lane%8)
+    int xpix[NXP];        // pixel index relative to image img0 (or -1: zero row)
+    int xchk[NXP];        // byte offset of the channel chunk this lane fetches (swizzled)
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+        const int hr = (wave + 8 * i) * 8 + (lane >> 3);
+        const int seg = hr / SEGSZ, rem = hr - seg * SEGSZ;
+        const int hy = rem / PW, hx = rem - hy * PW;
+        const int y = y0 + hy - 1, x = hx - 1;
+        const bool ok = seg < SEG && img0 + seg < p.nimg && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd;
+        xpix[i] = ok ? seg * HW + y * Wd + x : -1;
+        xchk[i] = ((lane & 7) ^ swz(hr)) * 16;
+    }
+    unsigned wvo[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int rw = (wave + 8 * i) * 8 + (lane >> 3);
+        wvo[i] = (unsigned)(rw * p.ldw * 2 + (((lane & 7) ^ swz(rw)) * 16));
+    }
+    const __amdgpu_buffer_rsrc_t rs_x1 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long long)img0 * HW * p.ldx), 0, kRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.X2 ? p.X2 + (long long)img0 * HW * p.ldx2 : p.X), 0, kRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.ldw), 0, kRecords, 0x00020000);
+
+    auto stage_x = [&](int cs) {
+        // channel slab cs of the concatenated input: source 1 holds channels [0, C1), source 2 the rest
+        const bool s2 = cs * 64 >= p.C1;
+        const int ld2 = 2 * (s2 ? p.ldx2 : p.ldx);
+        const int soff = 2 * (s2 ? cs * 64 - p.C1 : cs * 64);
+        const __amdgpu_buffer_rsrc_t rs = s2 ? rs_x2 : rs_x1;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const unsigned vo = xpix[i] >= 0 ? (unsigned)(xpix[i] * ld2 + xchk[i]) : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsX + (wave + 8 * i) * 1024), 16,
+                                                     (int)vo, soff, 0, 0);
+        }
+    };
+    auto stage_w = [&](int buf, int cs, int tap) {
+        const int soff = 2 * (tap * K + cs * 64);
+        char* const base = ldsW + buf * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (wave + 8 * i) * 1024), 16,
+                                                     (int)wvo[i], soff, 0, 0);
+    };
+
+    // ---- fragment addresses ----
+    int hrow0[TM];          // halo row of this lane's pixel of m-tile mt, centre tap
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int t = wm * 64 + mt * 32 + l31;
+        const int seg = t / SEGPX, r = t - seg * SEGPX;
+        const int ry = r / Wd, x = r - ry * Wd;
+        hrow0[mt] = seg * SEGSZ + (ry + 1) * PW + (x + 1);
+    }
+    int wfo[KSTEPS];        // W fragment: row wn*160 + nt*32 + l31 (the n-tile part is an immediate offset)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) wfo[ks] = (wn * 160 + l31) * ROWB + (((ks * 2 + lhi) ^ swz(l31)) << 4);
+
+    f32x16_t acc[TN][TM];
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nt][mt][e] = 0.f;
+
+    auto compute = [&](int tap, int buf) {
+        const int toff = (tap / 3 - 1) * PW + (tap - (tap / 3) * 3 - 1);
+        int xbase[TM], xs[TM];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int hr = hrow0[mt] + toff;
+            xbase[mt] = hr * ROWB;
+            xs[mt] = swz(hr);
+        }
+        const char* const wb = ldsW + buf * W_BYTES;
+        auto xfrag = [&](int ks, int mt) __attribute__((always_inline)) {
+            return *(const bf16x8_t*)(ldsX + xbase[mt] + (((ks * 2 + lhi) ^ xs[mt]) << 4));
+        };
+        auto wfrag = [&](int st) __attribute__((always_inline)) {
+            return *(const bf16x8_t*)(wb + wfo[st / TN] + (st % TN) * 32 * ROWB);
+        };
+        // rotating W fragments, as the bf16 K loop of the igemm (sdv_gemm.hip, SDV_BF16_ROT_AH)
+        constexpr int AH = 2, STEPS = KSTEPS * TN;
+        bf16x8_t xa[2][TM], wq[AH + 1];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) xa[0][mt] = xfrag(0, mt);
+#pragma unroll
+        for (int a = 0; a < AH; ++a) wq[a] = wfrag(a);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int ks = st / TN, nt = st % TN;
+            if (st + AH < STEPS) wq[(st + AH) % (AH + 1)] = wfrag(st + AH);
+            if (nt == TN - 1 - AH && ks + 1 < KSTEPS) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) xa[(ks + 1) & 1][mt] = xfrag(ks + 1, mt);
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[st % (AH + 1)], xa[ks & 1][mt], acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- K loop: channel slabs outside, taps inside ----
+    const int ncs = K / 64;
+    stage_x(0);
+    stage_w(0, 0, 0);
+    int buf = 0;
+    for (int cs = 0; cs < ncs; ++cs) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();        // this tap's W slab (and, tap 0, the X window) landed; every wave is past the previous tap
+            int ntap = tap + 1, ncsl = cs;
+            if (ntap == 9) {
+                ntap = 0;
+                ++ncsl;
+            }
+            if (ncsl < ncs) stage_w(buf ^ 1, ncsl, ntap);
+            compute(tap, buf);
+            buf ^= 1;
+        }
+#ifndef HALO_WHATIF_NO_X_RESTAGE   // (timing-only what-if build: wrong results)
+        if (cs + 1 < ncs) {
+            __syncthreads();        // every wave has read the X window of this slab for the last time
+            stage_x(cs + 1);
+        }
+#endif
+    }
+
+    // ---- epilogue straight from the MFMA layout: lane (l31, lhi) holds, per (nt, mt), pixel l31 x channels (r&3) + 8 (r>>2) + 4 lhi ----
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const long long m = (long long)m0 + wm * 64 + mt * 32 + l31;
+#ifdef HALO_WHATIF_NO_EPILOGUE      // (timing-only what-if build: nothing is stored unless an accumulator is exactly 12345)
+        if (acc[0][mt][0] != 12345.f) continue;
+#endif
+        if (m >= M) continue;
+        uint16_t* const crow = p.C + m * p.ldc;
+        const uint16_t* const rrow = p.R ? p.R + m * p.ldr : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            u32x2_t rr[4];
+            if (rrow) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rr[q] = *(const u32x2_t*)(rrow + n0 + wn * 160 + nt * 32 + 8 * q + 4 * lhi);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = n0 + wn * 160 + nt * 32 + 8 * q + 4 * lhi;
+                const float4 b = *(const float4*)(p.bias + c0);
+                float v[4] = {acc[nt][mt][4 * q] + b.x, acc[nt][mt][4 * q + 1] + b.y, acc[nt][mt][4 * q + 2] + b.z,
+                              acc[nt][mt][4 * q + 3] + b.w};
+                if (rrow) {
+                    v[0] += __uint_as_float(rr[q][0] << 16);
+                    v[1] += __uint_as_float(rr[q][0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rr[q][1] << 16);
+                    v[3] += __uint_as_float(rr[q][1] & 0xffff0000u);
+                }
+                *(u32x2_t*)(crow + c0) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sdv_conv3x3_halo_bf16(const sdv_bf16* X, const sdv_bf16* X2, const sdv_bf16* W, const float* bias, const sdv_bf16* R,
+                                     sdv_bf16* C, int32_t nimg, int32_t H, int32_t Wd, int32_t C1, int32_t C2, int32_t Cout,
+                                     int32_t ldx, int32_t ldx2, int32_t ldw, int32_t ldr, int32_t ldc, const int32_t* step_ptr,
+                                     int32_t bias_step_stride, void* stream) {
+    SDV_REQUIRE(X && W && bias && C && nimg > 0 && H > 0 && Wd > 0, "sdv_conv3x3_halo_bf16: bad args");
+    SDV_REQUIRE(C1 > 0 && C1 % 64 == 0 && C2 >= 0 && C2 % 64 == 0 && (C2 == 0 || X2), "sdv_conv3x3_halo_bf16: channel counts must be multiples of 64");
+    SDV_REQUIRE(Cout % BN == 0, "sdv_conv3x3_halo_bf16: Cout=%d must be a multiple of %d", Cout, BN);
+    const int HW = H * Wd;
+    SDV_REQUIRE(BM % Wd == 0 && (HW % BM == 0 || BM % HW == 0), "sdv_conv3x3_halo_bf16: %d x %d images do not tile into %d-pixel row blocks", H, Wd, BM);
+    {   // the halo window must fit the staged rows
+        const int seg = HW >= BM ? 1 : BM / HW, rs = HW >= BM ? BM / Wd : H;
+        SDV_REQUIRE(seg * (rs + 2) * (Wd + 2) <= XROWS, "sdv_conv3x3_halo_bf16: window of %d x %d images exceeds %d halo rows", H, Wd, XROWS);
+    }
+    SDV_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0) && (C2 == 0 || ldx2 % 8 == 0), "sdv_conv3x3_halo_bf16: unaligned leading dims");
+    SDV_REQUIRE((long long)HW * 4 * (ldx > ldx2 ? ldx : ldx2) * 2 < 0x7fffffffLL, "sdv_conv3x3_halo_bf16: tile window exceeds 31-bit offsets");
+    static bool attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set[dev] = true;
+    }
+    HaloArgs a;
+    a.X = X;
+    a.X2 = X2;
+    a.W = W;
+    a.bias = bias;   // the step-table row is selected on the device side below (graph-replayable)
+    a.R = R;
+    a.C = C;
+    a.nimg = nimg, a.H = H, a.Wd = Wd, a.C1 = C1, a.C2 = C2, a.Cout = Cout;
+    a.ldx = ldx, a.ldx2 = ldx2, a.ldw = ldw, a.ldr = ldr, a.ldc = ldc;
+    SDV_REQUIRE(step_ptr == nullptr || bias_step_stride == 0, "sdv_conv3x3_halo_bf16: the per-step bias table is not wired yet (prototype)");
+    const long long M = (long long)nimg * HW;
+    const long long tiles = ((M + BM - 1) / BM) * (Cout / BN);
+    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)tiles), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+    SDV_CHECK_LAUNCH("sdv_conv3x3_halo_bf16");
+    return SDV_OK;
+}
