@@ -21,7 +21,9 @@ import os  # noqa: E402
 SRC = ROOT / "tools" / "experiments" / "sdv_conv_halo.hip"
 # HALO_DEFS="-DHALO_WHATIF_NO_EPILOGUE": timing-only what-if builds of the prototype (their outputs are wrong by construction)
 DEFS = os.environ.get("HALO_DEFS", "").split()
-LIB = ROOT / "tools" / "ubench" / ("libsdv_conv_halo" + "".join(d.replace("-D", "_").lower() for d in DEFS) + ".so")
+# HALO_AGPR=1: compile without -amdgpu-mfma-vgpr-form (accumulators in AccVGPRs)
+VGPR_FORM = [] if os.environ.get("HALO_AGPR") == "1" else ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+LIB = ROOT / "tools" / "ubench" / ("libsdv_conv_halo" + "".join(d.replace("-D", "_").lower() for d in DEFS) + ("" if VGPR_FORM else "_agpr") + ".so")
 
 
 def build():
@@ -29,7 +31,7 @@ def build():
         return
     b.build()
     obj = LIB.with_suffix(".o")
-    subprocess.run([b.hipcc(), *b.FLAGS, *b.FAST_FLAGS, "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", str(b.CSRC), *DEFS, "-c", str(SRC), "-o", str(obj)],
+    subprocess.run([b.hipcc(), *b.FLAGS, *b.FAST_FLAGS, *VGPR_FORM, "-I", str(b.CSRC), *DEFS, "-c", str(SRC), "-o", str(obj)],
                    check=True)
     subprocess.run([b.hipcc(), "--offload-arch=" + b.ARCH, "-shared", "-fPIC", str(obj), str(b.OBJDIR / "sdv_elementwise.o"), "-o", str(LIB)],
                    check=True)

@@ -149,6 +149,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
         auto wfrag = [&](int st) __attribute__((always_inline)) {
             return *(const bf16x8_t*)(wb + wfo[st / TN] + (st % TN) * 32 * ROWB);
         };
+#ifdef HALO_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         // rotating W fragments, as the bf16 K loop of the igemm (sdv_gemm.hip, SDV_BF16_ROT_AH)
         constexpr int AH = 2, STEPS = KSTEPS * TN;
         bf16x8_t xa[2][TM], wq[AH + 1];
@@ -169,6 +172,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[st % (AH + 1)], xa[ks & 1][mt], acc[nt][mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef HALO_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- K loop: channel slabs outside, taps inside ----
