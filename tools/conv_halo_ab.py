@@ -64,7 +64,10 @@ def main():
              ("conv 1280+1280->1280 @16", 16, 1280, 1280, 1280, False)]
     print(f"nimg={nimg} rounds={rounds}   TFLOP/s median (min..max): shipped igemm tile 6 | halo-tile prototype")
     stream = torch.cuda.current_stream().cuda_stream
+    bn = 64 * int(next((d.split("=")[1] for d in DEFS if d.startswith("-DHALO_TN=")), "5"))     # the prototype's N tile
     for label, H, c1, c2, cout, use_res in cases:
+        if cout % bn:
+            continue
         M, K = nimg * H * H, c1 + c2
         g = torch.Generator(device=dev).manual_seed(1)
         x = (torch.randn((M, c1), device=dev, generator=g) * 0.5).to(torch.bfloat16)

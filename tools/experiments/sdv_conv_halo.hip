@@ -20,9 +20,18 @@ namespace {
 
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int kRecords = 0x7ffffff0;
-constexpr int BM = 256, BN = 320, ROWB = 128, KSTEPS = 4, TM = 2, TN = 5;
-constexpr int NXP = 7, NWP = 5;                   // LDS-DMA pieces (1 KB = 8 rows) per wave: X window (56 >= 50), W slab (40)
-constexpr int XROWS = 8 * 8 * NXP;                // 448 rows staged (the layouts use <= 400; surplus pieces read zeros)
+#ifdef HALO_WAVES4   // sandbox: ONE wave per SIMD, wave tile 128 x 160 (TM 4 x TN 5 = 320 accumulator registers -> AccVGPRs)
+constexpr int NWAVE = 4, TM = 4;
+#else
+constexpr int NWAVE = 8, TM = 2;
+#endif
+#ifndef HALO_TN
+#define HALO_TN 5
+#endif
+constexpr int TN = HALO_TN;                        // n-tiles per wave (sandbox: 4 -> 256-column tiles, 16 accumulator tiles = 256 AccVGPRs)
+constexpr int BM = 256, BN = 2 * TN * 32, ROWB = 128, KSTEPS = 4;
+constexpr int NXP = 56 / NWAVE, NWP = BN / 8 / NWAVE;  // LDS-DMA pieces (1 KB = 8 rows) per wave: X window (56 >= 50), W slab (40)
+constexpr int XROWS = 8 * 56;                      // 448 rows staged (the layouts use <= 400; surplus pieces read zeros)
 constexpr int X_BYTES = XROWS * ROWB;             // 57344
 constexpr int W_BYTES = BN * ROWB;                // 40960
 constexpr int LDS_BYTES = X_BYTES + 2 * W_BYTES;  // 139264
@@ -39,7 +48,7 @@ struct HaloArgs {
 
 __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
+__global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsX = smem;
     char* const ldsW = smem + X_BYTES;
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
     int xchk[NXP];        // byte offset of the channel chunk this lane fetches (swizzled)
 #pragma unroll
     for (int i = 0; i < NXP; ++i) {
-        const int hr = (wave + 8 * i) * 8 + (lane >> 3);
+        const int hr = (wave + NWAVE * i) * 8 + (lane >> 3);
         const int seg = hr / SEGSZ, rem = hr - seg * SEGSZ;
         const int hy = rem / PW, hx = rem - hy * PW;
         const int y = y0 + hy - 1, x = hx - 1;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
     unsigned wvo[NWP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
-        const int rw = (wave + 8 * i) * 8 + (lane >> 3);
+        const int rw = (wave + NWAVE * i) * 8 + (lane >> 3);
         wvo[i] = (unsigned)(rw * p.ldw * 2 + (((lane & 7) ^ swz(rw)) * 16));
     }
     const __amdgpu_buffer_rsrc_t rs_x1 =
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
             const unsigned vo = xpix[i] >= 0 ? (unsigned)(xpix[i] * ld2 + xchk[i]) : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsX + (wave + 8 * i) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsX + (wave + NWAVE * i) * 1024), 16,
                                                      (int)vo, soff, 0, 0);
         }
     };
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
         char* const base = ldsW + buf * W_BYTES;
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (wave + 8 * i) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (wave + NWAVE * i) * 1024), 16,
                                                      (int)wvo[i], soff, 0, 0);
     };
 
@@ -116,14 +125,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
     int hrow0[TM];          // halo row of this lane's pixel of m-tile mt, centre tap
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
-        const int t = wm * 64 + mt * 32 + l31;
+        const int t = wm * (TM * 32) + mt * 32 + l31;
         const int seg = t / SEGPX, r = t - seg * SEGPX;
         const int ry = r / Wd, x = r - ry * Wd;
         hrow0[mt] = seg * SEGSZ + (ry + 1) * PW + (x + 1);
     }
     int wfo[KSTEPS];        // W fragment: row wn*160 + nt*32 + l31 (the n-tile part is an immediate offset)
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) wfo[ks] = (wn * 160 + l31) * ROWB + (((ks * 2 + lhi) ^ swz(l31)) << 4);
+    for (int ks = 0; ks < KSTEPS; ++ks) wfo[ks] = (wn * (TN * 32) + l31) * ROWB + (((ks * 2 + lhi) ^ swz(l31)) << 4);
 
     f32x16_t acc[TN][TM];
 #pragma unroll
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
     // ---- epilogue straight from the MFMA layout: lane (l31, lhi) holds, per (nt, mt), pixel l31 x channels (r&3) + 8 (r>>2) + 4 lhi ----
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
-        const long long m = (long long)m0 + wm * 64 + mt * 32 + l31;
+        const long long m = (long long)m0 + wm * (TM * 32) + mt * 32 + l31;
 #ifdef HALO_WHATIF_NO_EPILOGUE      // (timing-only what-if build: nothing is stored unless an accumulator is exactly 12345)
         if (acc[0][mt][0] != 12345.f) continue;
 #endif
@@ -219,11 +228,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const HaloArgs p) {
             u32x2_t rr[4];
             if (rrow) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rr[q] = *(const u32x2_t*)(rrow + n0 + wn * 160 + nt * 32 + 8 * q + 4 * lhi);
+                for (int q = 0; q < 4; ++q) rr[q] = *(const u32x2_t*)(rrow + n0 + wn * (TN * 32) + nt * 32 + 8 * q + 4 * lhi);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c0 = n0 + wn * 160 + nt * 32 + 8 * q + 4 * lhi;
+                const int c0 = n0 + wn * (TN * 32) + nt * 32 + 8 * q + 4 * lhi;
                 const float4 b = *(const float4*)(p.bias + c0);
                 float v[4] = {acc[nt][mt][4 * q] + b.x, acc[nt][mt][4 * q + 1] + b.y, acc[nt][mt][4 * q + 2] + b.z,
                               acc[nt][mt][4 * q + 3] + b.w};
@@ -275,7 +284,7 @@ extern "C" int sdv_conv3x3_halo_bf16(const sdv_bf16* X, const sdv_bf16* X2, cons
     SDV_REQUIRE(step_ptr == nullptr || bias_step_stride == 0, "sdv_conv3x3_halo_bf16: the per-step bias table is not wired yet (prototype)");
     const long long M = (long long)nimg * HW;
     const long long tiles = ((M + BM - 1) / BM) * (Cout / BN);
-    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)tiles), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)tiles), dim3(NWAVE * 64), LDS_BYTES, (hipStream_t)stream, a);
     SDV_CHECK_LAUNCH("sdv_conv3x3_halo_bf16");
     return SDV_OK;
 }
