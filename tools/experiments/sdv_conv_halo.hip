@@ -14,6 +14,8 @@
 // (channels), wave tile 64 x 160 = TM 2 x TN 5 accumulators of v_mfma_f32_32x32x16_bf16 (A = W rows, B = pixels - the layout of
 // the igemm, so the results differ from it only by the order the (channel slab, tap) partial sums are accumulated in).
 // LDS rows are 128 B (64 channels) with the igemm's XOR swizzle: position (row, chunk') holds channel chunk chunk' ^ ((row >> 1) & 7).
+#include <type_traits>
+
 #include "sdv_common.h"
 
 namespace {
@@ -213,6 +215,86 @@ __global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs
 #endif
     }
 
+#ifdef HALO_ROWMAJOR_EPILOGUE
+    // ---- row-major epilogue (the igemm's idea, in its plainest form): a pass = 32 pixels x 64 channels (bf16 slab; 32 channels as fp32
+    //      when a residual has to be added before the single rounding) goes through a wave-private LDS slab (rows of 128 B + 16 B
+    //      pad) and leaves as 16-byte stores - 8 adjacent lanes write one pixel's 128 contiguous bytes.  Two slabs per wave. ----
+    __syncthreads();                                   // every wave is past its last fragment read: the W buffers become staging slabs
+    {
+        typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) slab_u4;
+        typedef unsigned int __attribute__((ext_vector_type(2), may_alias)) slab_u2;
+        char* const slab0 = ldsW + wave * 2 * 4608;
+        // straight-line code per case (every pass index is a compile-time constant: the accumulators are never indexed dynamically)
+        auto run = [&](auto hasr_tag) {
+            constexpr bool has_r = decltype(hasr_tag)::value;
+            constexpr int NPP = has_r ? TN : (TN + 1) / 2;     // passes per m-tile
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const long long mrow0 = (long long)m0 + wm * (TM * 32) + mt * 32;
+#pragma unroll
+                for (int pp = 0; pp < NPP; ++pp) {
+                    char* const slab = slab0 + ((mt * NPP + pp) & 1) * 4608;
+                    const int nt0 = has_r ? pp : 2 * pp;
+                    const int cnt = has_r ? 1 : (TN - nt0 < 2 ? TN - nt0 : 2);
+                    // phase 1: bias in the MFMA layout, park
+#pragma unroll
+                    for (int k = 0; k < cnt; ++k) {
+                        const int nt = nt0 + k;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c0 = n0 + wn * (TN * 32) + nt * 32 + 8 * q + 4 * lhi;
+                            const float4 b = *(const float4*)(p.bias + c0);
+                            const float v[4] = {acc[nt][mt][4 * q] + b.x, acc[nt][mt][4 * q + 1] + b.y, acc[nt][mt][4 * q + 2] + b.z,
+                                                acc[nt][mt][4 * q + 3] + b.w};
+                            const int cl = k * 32 + 8 * q + 4 * lhi;
+                            if constexpr (has_r)
+                                *(slab_u4*)(slab + l31 * 144 + cl * 4) =
+                                    slab_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                            else
+                                *(slab_u2*)(slab + l31 * 144 + cl * 2) = slab_u2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    // phase 2: rows back out, 16 bytes per lane
+                    const int col0 = n0 + wn * (TN * 32) + nt0 * 32;
+                    if constexpr (has_r) {
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const int idx = lane + 64 * it, r = idx >> 2, cj = idx & 3;
+                            const long long m = mrow0 + r;
+                            const slab_u4 lo = *(const slab_u4*)(slab + r * 144 + cj * 32), hi = *(const slab_u4*)(slab + r * 144 + cj * 32 + 16);
+                            if (m < M) {
+                                const u32x4_t rr = *(const u32x4_t*)(p.R + m * p.ldr + col0 + cj * 8);
+                                float f[8] = {__uint_as_float(lo[0]), __uint_as_float(lo[1]), __uint_as_float(lo[2]), __uint_as_float(lo[3]),
+                                              __uint_as_float(hi[0]), __uint_as_float(hi[1]), __uint_as_float(hi[2]), __uint_as_float(hi[3])};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    f[2 * e] += __uint_as_float(rr[e] << 16);
+                                    f[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                                }
+                                *(u32x4_t*)(p.C + m * p.ldc + col0 + cj * 8) =
+                                    u32x4_t{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+                            }
+                        }
+                    } else {
+                        const int cpo = cnt * 4;            // 8-column groups per row: 8 or 4
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            if (it * 64 >= 32 * cpo) continue;
+                            const int idx = lane + 64 * it, r = idx / cpo, cj = idx - r * cpo;
+                            const long long m = mrow0 + r;
+                            const slab_u4 d = *(const slab_u4*)(slab + r * 144 + cj * 16);
+                            if (m < M) *(u32x4_t*)(p.C + m * p.ldc + col0 + cj * 8) = u32x4_t{d[0], d[1], d[2], d[3]};
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+        };
+        if (p.R) run(std::true_type{});
+        else run(std::false_type{});
+    }
+#else
     // ---- epilogue straight from the MFMA layout: lane (l31, lhi) holds, per (nt, mt), pixel l31 x channels (r&3) + 8 (r>>2) + 4 lhi ----
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -246,6 +328,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs
             }
         }
     }
+#endif
 }
 
 }  // namespace
