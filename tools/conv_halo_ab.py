@@ -18,12 +18,13 @@ from stable_diffusion_videos_amd import hip  # noqa: E402
 
 import os  # noqa: E402
 
-SRC = ROOT / "tools" / "experiments" / "sdv_conv_halo.hip"
+# HALO_SRC=sdv_conv_halo_persistent.hip: the tile-walk variant (persistent with -DHALO_PERSISTENT)
+SRC = ROOT / "tools" / "experiments" / os.environ.get("HALO_SRC", "sdv_conv_halo.hip")
 # HALO_DEFS="-DHALO_WHATIF_NO_EPILOGUE": timing-only what-if builds of the prototype (their outputs are wrong by construction)
 DEFS = os.environ.get("HALO_DEFS", "").split()
 # HALO_AGPR=1: compile without -amdgpu-mfma-vgpr-form (accumulators in AccVGPRs)
 VGPR_FORM = [] if os.environ.get("HALO_AGPR") == "1" else ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-LIB = ROOT / "tools" / "ubench" / ("libsdv_conv_halo" + "".join(d.replace("-D", "_").lower() for d in DEFS) + ("" if VGPR_FORM else "_agpr") + ".so")
+LIB = ROOT / "tools" / "ubench" / ("lib" + SRC.stem + "".join(d.replace("-D", "_").lower() for d in DEFS) + ("" if VGPR_FORM else "_agpr") + ".so")
 
 
 def build():
