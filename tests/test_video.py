@@ -411,3 +411,20 @@ def test_exp_golomb_codes_known_answers():
         a, b = BitWriter(), BitWriter()
         a.se(v), b.ue(k)
         assert a.bits == b.bits
+
+
+def test_codec_selection_and_odd_sizes(tmp_path, monkeypatch):
+    """``SDV_VIDEO_CODEC`` picks the dependency-free writer's codec; yuv420p needs even sizes, so odd frames fall back to
+    Motion-JPEG (the reference's libx264 call would fail on them: "height not divisible by 2"); unknown names are an error."""
+    odd = torch.randint(0, 255, (2, 3, 33, 48), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    monkeypatch.delenv("SDV_VIDEO_CODEC", raising=False)
+    buf = open(make_video_pyav(odd, fps=8, output_filepath=tmp_path / "odd.mp4"), "rb").read()
+    lo, hi = find(buf, ("moov", "trak", "mdia", "minf", "stbl", "stsd"))
+    assert parse_boxes(buf, lo + 8, hi)[0][0] == "mp4v"
+    even = odd[:, :, :32]
+    buf = open(make_video_pyav(even, fps=8, output_filepath=tmp_path / "even.mp4"), "rb").read()
+    lo, hi = find(buf, ("moov", "trak", "mdia", "minf", "stbl", "stsd"))
+    assert parse_boxes(buf, lo + 8, hi)[0][0] == "avc1"
+    monkeypatch.setenv("SDV_VIDEO_CODEC", "vp9")
+    with pytest.raises(ValueError, match="SDV_VIDEO_CODEC"):
+        make_video_pyav(even, fps=8, output_filepath=tmp_path / "x.mp4")
