@@ -11,7 +11,8 @@ diffusers 0.11-0.14.  The architecture restated here is the published SD-v1 / SD
 schema so a real checkpoint directory can be loaded.  **parity
 unpinned** for the UNet (no reference golden vectors exist for these modules); the VAE ``Decoder`` is pinned
 against third-party code - the CompVis ``ldm`` Decoder shipped in ``transformers`` (JanusVQVAEDecoder) through the
-published ldm -> diffusers weight conversion, tests/test_oracle.py::test_vae_decoder_pinned_against_the_ldm_decoder_in_transformers.
+published ldm -> diffusers weight conversion, tests/test_oracle.py::test_vae_decoder_pinned_against_the_ldm_decoder_in_transformers;
+``BasicTransformerBlock`` is pinned against torch's own ``nn.TransformerDecoderLayer(norm_first=True)`` (same file).
 
 Layout here is plain NCHW fp32 and nn.functional ops - deliberately the most literal form, so it
 can serve as the checker for the NHWC/bf16 HIP path.

@@ -360,3 +360,56 @@ def test_vae_decoder_pinned_against_the_ldm_decoder_in_transformers():
         assert float((ldm.up[1].upsample(x.clone()) - ours.up_blocks[1].upsamplers[0](x)).abs().max()) < 1e-4
         x2 = torch.randn(2, 512, 8, 8)
         assert float((ldm.up[2].block[0](x2.clone()) - ours.up_blocks[2].resnets[0](x2)).abs().max()) < 1e-4   # 512 -> 256, nin_shortcut
+
+
+def test_basic_transformer_block_pinned_against_torch_transformer_decoder_layer():
+    """A THIRD-PARTY pin for row a12 ([3P] ``BasicTransformerBlock``): torch's own ``nn.TransformerDecoderLayer`` with
+    ``norm_first=True`` IS the block's data flow - x + SelfAttn(LN1 x), x + CrossAttn(LN2 x, context), x + FF(LN3 x), LayerNorm eps
+    1e-5 - executed by code written by other people (``nn.MultiheadAttention``: packed q/k/v projection, the split into heads,
+    1/sqrt(dh), softmax, merge, out projection with bias).  The two places diffusers differs are configured, not re-implemented:
+    a context of another width (``kdim`` / ``vdim``) and the GEGLU feed-forward (``activation`` = value * exact GELU of the gate on
+    ``linear1``'s fused output).  Random weights carried over by name; q / k / v have no bias in diffusers, so the in-projection
+    biases are zero."""
+    from oracle import models
+    torch.manual_seed(5)
+    d, heads, dh, ctx_dim, inner = 48, 4, 12, 40, 192
+    ours = models.BasicTransformerBlock(d, heads, dh, ctx_dim).double().eval()
+    with torch.no_grad():
+        for n, p in ours.named_parameters():
+            p.copy_(torch.randn(p.shape, dtype=torch.float64) * (0.15 if p.ndim > 1 else 0.3))
+            if "norm" in n and n.endswith("weight"):
+                p.add_(1.0)
+    ref = torch.nn.TransformerDecoderLayer(d, heads, dim_feedforward=2 * inner, dropout=0.0, batch_first=True, norm_first=True,
+                                           activation=lambda h: h[..., :inner] * torch.nn.functional.gelu(h[..., inner:]))
+    ref.multihead_attn = torch.nn.MultiheadAttention(d, heads, dropout=0.0, batch_first=True, kdim=ctx_dim, vdim=ctx_dim)
+    ref.linear2 = torch.nn.Linear(inner, d)
+    ref = ref.double().eval()
+    with torch.no_grad():
+        a1, a2 = ours.attn1, ours.attn2
+        ref.self_attn.in_proj_weight.copy_(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight]))
+        ref.self_attn.in_proj_bias.zero_()
+        ref.self_attn.out_proj.weight.copy_(a1.to_out[0].weight)
+        ref.self_attn.out_proj.bias.copy_(a1.to_out[0].bias)
+        ref.multihead_attn.q_proj_weight.copy_(a2.to_q.weight)
+        ref.multihead_attn.k_proj_weight.copy_(a2.to_k.weight)
+        ref.multihead_attn.v_proj_weight.copy_(a2.to_v.weight)
+        ref.multihead_attn.in_proj_bias.zero_()
+        ref.multihead_attn.out_proj.weight.copy_(a2.to_out[0].weight)
+        ref.multihead_attn.out_proj.bias.copy_(a2.to_out[0].bias)
+        for k in (1, 2, 3):
+            getattr(ref, f"norm{k}").weight.copy_(getattr(ours, f"norm{k}").weight)
+            getattr(ref, f"norm{k}").bias.copy_(getattr(ours, f"norm{k}").bias)
+        ref.linear1.weight.copy_(ours.ff.net[0].proj.weight)
+        ref.linear1.bias.copy_(ours.ff.net[0].proj.bias)
+        ref.linear2.weight.copy_(ours.ff.net[2].weight)
+        ref.linear2.bias.copy_(ours.ff.net[2].bias)
+        x = torch.randn(3, 20, d, dtype=torch.float64)
+        ctx = torch.randn(3, 7, ctx_dim, dtype=torch.float64) * 2.0
+        got, want = ours(x, ctx), ref(x, ctx)
+    assert got.shape == want.shape == (3, 20, d)
+    assert float((got - want).abs().max()) < 1e-10 * float(want.abs().max())
+    # ... and the comparison has teeth: swapping the GEGLU halves or dropping the softmax scale is far outside it
+    with torch.no_grad():
+        w = ours.ff.net[0].proj.weight.clone()
+        ours.ff.net[0].proj.weight.copy_(torch.cat([w[inner:], w[:inner]]))
+        assert float((ours(x, ctx) - want).abs().max()) > 1e-2
