@@ -1,8 +1,7 @@
 // TILE-WALK VARIANT of sdv_conv_halo.hip (one loop over tiles per workgroup; -DHALO_PERSISTENT launches one workgroup per CU, the next
 // tile's X window streams in behind the epilogue).  Correct (tools/conv_halo_ab.py, HALO_SRC=sdv_conv_halo_persistent.hip), but the
-// addressing state kept alive across the epilogue costs 120 B of scratch per lane at the tile boundary and the variant is 3-6 % SLOWER
-// than the one-tile-per-workgroup file, persistent or not (profiles/round3_conv_halo_prototype.txt) - it needs the register discipline of
-// the shipped igemm (lane-derived state re-derived per tile from an opaque copy).
+// variant is 0-6 % SLOWER than the one-tile-per-workgroup file, persistent or not (profiles/round3_conv_halo_prototype.txt) - also with
+// the register discipline of the shipped igemm applied (lane-derived state re-derived per tile from an opaque copy: 120 -> 36 B of scratch).
 //
 // conv3x3 (stride 1, pad 1, NHWC bf16) with the input window staged ONCE per channel slab - the "halo tile" form of the
 // implicit GEMM in sdv_gemm.hip, for the ResBlock convolutions of UNet2DConditionModel / AutoencoderKL
@@ -81,48 +80,44 @@ __global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs
     // X window piece g = wave + 8 i covers halo rows g*8 .. g*8+7; lane -> (row g*8 + lane/8, LDS chunk lane%8)
     int xpix[NXP];        // pixel index relative to image img0 (or -1: zero row)
     int xchk[NXP];        // byte offset of the channel chunk this lane fetches (swizzled)
-#pragma unroll
-    for (int i = 0; i < NXP; ++i) xchk[i] = ((lane & 7) ^ swz((wave + NWAVE * i) * 8 + (lane >> 3))) * 16;
-    int m0 = 0, n0 = 0;   // the tile the ADDRESSING points at (persistent walk: re-pointed at the next tile ahead of the epilogue)
+    int m0 = 0, n0 = 0;   // the tile the ADDRESSING points at
     __amdgpu_buffer_rsrc_t rs_x1, rs_x2, rs_w;
-    auto setup_tile = [&](int tile) {
+    // (everything derived from the lane id is re-derived per tile from an OPAQUE copy of it, so that none of it stays alive across
+    //  the epilogue, where the 160 accumulators + the staging state fill the register file - the igemm's discipline)
+    auto tile_window = [&](int tile, int lk, int* xp, int* xc, __amdgpu_buffer_rsrc_t& r1, __amdgpu_buffer_rsrc_t& r2, int& tm0, int& tn0) {
         const int bn = tile % tiles_n, bm = tile / tiles_n;
-        m0 = bm * BM;
-        n0 = bn * BN;
-        const int img0 = m0 / HW;
-        const int y0 = (m0 - img0 * HW) / Wd;            // first image row of the tile (0 when SEG > 1)
+        tm0 = bm * BM;
+        tn0 = bn * BN;
+        const int img0 = tm0 / HW;
+        const int y0 = (tm0 - img0 * HW) / Wd;            // first image row of the tile (0 when SEG > 1)
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
-            const int hr = (wave + NWAVE * i) * 8 + (lane >> 3);
+            const int hr = (wave + NWAVE * i) * 8 + (lk >> 3);
             const int seg = hr / SEGSZ, rem = hr - seg * SEGSZ;
             const int hy = rem / PW, hx = rem - hy * PW;
             const int y = y0 + hy - 1, x = hx - 1;
             const bool ok = seg < SEG && img0 + seg < p.nimg && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd;
-            xpix[i] = ok ? seg * HW + y * Wd + x : -1;
+            xp[i] = ok ? seg * HW + y * Wd + x : -1;
+            xc[i] = ((lk & 7) ^ swz(hr)) * 16;
         }
-        rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long long)img0 * HW * p.ldx), 0, kRecords, 0x00020000);
-        rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X2 ? p.X2 + (long long)img0 * HW * p.ldx2 : p.X), 0, kRecords, 0x00020000);
-        rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.ldw), 0, kRecords, 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long long)img0 * HW * p.ldx), 0, kRecords, 0x00020000);
+        r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X2 ? p.X2 + (long long)img0 * HW * p.ldx2 : p.X), 0, kRecords, 0x00020000);
     };
     unsigned wvo[NWP];
-#pragma unroll
-    for (int i = 0; i < NWP; ++i) {
-        const int rw = (wave + NWAVE * i) * 8 + (lane >> 3);
-        wvo[i] = (unsigned)(rw * p.ldw * 2 + (((lane & 7) ^ swz(rw)) * 16));
-    }
-    auto stage_x = [&](int cs) {
+    auto stage_x_with = [&](int cs, const int* xp, const int* xc, const __amdgpu_buffer_rsrc_t& r1, const __amdgpu_buffer_rsrc_t& r2) {
         // channel slab cs of the concatenated input: source 1 holds channels [0, C1), source 2 the rest
         const bool s2 = cs * 64 >= p.C1;
         const int ld2 = 2 * (s2 ? p.ldx2 : p.ldx);
         const int soff = 2 * (s2 ? cs * 64 - p.C1 : cs * 64);
-        const __amdgpu_buffer_rsrc_t rs = s2 ? rs_x2 : rs_x1;
+        const __amdgpu_buffer_rsrc_t rs = s2 ? r2 : r1;
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
-            const unsigned vo = xpix[i] >= 0 ? (unsigned)(xpix[i] * ld2 + xchk[i]) : kOOB;
+            const unsigned vo = xp[i] >= 0 ? (unsigned)(xp[i] * ld2 + xc[i]) : kOOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsX + (wave + NWAVE * i) * 1024), 16,
                                                      (int)vo, soff, 0, 0);
         }
     };
+    auto stage_x = [&](int cs) { stage_x_with(cs, xpix, xchk, rs_x1, rs_x2); };
     auto stage_w = [&](int buf, int cs, int tap) {
         const int soff = 2 * (tap * K + cs * 64);
         char* const base = ldsW + buf * W_BYTES;
@@ -134,16 +129,24 @@ __global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs
 
     // ---- fragment addresses ----
     int hrow0[TM];          // halo row of this lane's pixel of m-tile mt, centre tap
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-        const int t = wm * (TM * 32) + mt * 32 + l31;
-        const int seg = t / SEGPX, r = t - seg * SEGPX;
-        const int ry = r / Wd, x = r - ry * Wd;
-        hrow0[mt] = seg * SEGSZ + (ry + 1) * PW + (x + 1);
-    }
     int wfo[KSTEPS];        // W fragment: row wn*160 + nt*32 + l31 (the n-tile part is an immediate offset)
+    auto lane_state = [&](int lk) {
+        const int k31 = lk & 31, khi = lk >> 5;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) wfo[ks] = (wn * (TN * 32) + l31) * ROWB + (((ks * 2 + lhi) ^ swz(l31)) << 4);
+        for (int mt = 0; mt < TM; ++mt) {
+            const int t = wm * (TM * 32) + mt * 32 + k31;
+            const int seg = t / SEGPX, r = t - seg * SEGPX;
+            const int ry = r / Wd, x = r - ry * Wd;
+            hrow0[mt] = seg * SEGSZ + (ry + 1) * PW + (x + 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) wfo[ks] = (wn * (TN * 32) + k31) * ROWB + (((ks * 2 + khi) ^ swz(k31)) << 4);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int rw = (wave + NWAVE * i) * 8 + (lk >> 3);
+            wvo[i] = (unsigned)(rw * p.ldw * 2 + (((lk & 7) ^ swz(rw)) * 16));
+        }
+    };
 
     f32x16_t acc[TN][TM];
 
@@ -194,10 +197,18 @@ __global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs
     // ---- tile walk (gridDim.x == number of tiles: one tile per workgroup; fewer workgroups: persistent) ----
     const int ncs = K / 64;
     int tile = blockIdx.x;
-    setup_tile(tile);
-    stage_x(0);
-    stage_w(0, 0, 0);
+    bool first = true;
     while (true) {
+    {
+        int lk = lane;
+        asm volatile("" : "+v"(lk));
+        lane_state(lk);
+        tile_window(tile, lk, xpix, xchk, rs_x1, rs_x2, m0, n0);
+        rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.ldw), 0, kRecords, 0x00020000);
+    }
+    if (first) stage_x(0);          // (later tiles: their first X window was fetched behind the previous tile's epilogue)
+    first = false;
+    stage_w(0, 0, 0);
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
@@ -232,9 +243,13 @@ __global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < ntiles;
     __syncthreads();                // every wave is past its last fragment read: X window and W buffers are free
-    if (has_next) {
-        setup_tile(next);
-        stage_x(0);
+    if (has_next) {                 // the next tile's first X window, from addressing state that dies right here
+        int lk = lane;
+        asm volatile("" : "+v"(lk));
+        int xp2[NXP], xc2[NXP], dm0, dn0;
+        __amdgpu_buffer_rsrc_t r1, r2;
+        tile_window(next, lk, xp2, xc2, r1, r2, dm0, dn0);
+        stage_x_with(0, xp2, xc2, r1, r2);
     }
 
 #ifdef HALO_ROWMAJOR_EPILOGUE
@@ -352,7 +367,6 @@ __global__ __launch_bounds__(NWAVE * 64) void conv3x3_halo_kernel(const HaloArgs
 #endif
     if (!has_next) break;
     __syncthreads();                // every wave has read its staging slabs back: the W buffers are free again
-    stage_w(0, 0, 0);
     tile = next;
     }   // tile walk
 }
