@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-walk-pass", action="store_true", help="skip the 60-frame walk() pass (frames/s including PNG files)")
     ap.add_argument("--no-kernel-pass", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the self-check of the last batch (frames recomputed at batch 4)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short passes of BASELINE configs 4 (SD-2.1 768x768) and 5 (fp8) that ride in `other_configs`")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="spawn the ranks, form the process group (gloo without GPUs), all-reduce once, print the line - no model")
     return ap.parse_args()
@@ -145,6 +148,90 @@ def launcher_selftest(args):
     parallel.barrier()
     if world > 1:
         dist.destroy_process_group()
+
+
+CONFIG3 = dict(prompts=["a cat", "a dog", "a horse", "a cow"], seeds=[42, 1337, 2022, 4321], counts=[80, 80, 80])
+
+
+def config3_plan(world: int, rank: int, B: int, counts=None):
+    """BASELINE.json configs[2] (4 prompts, 3 x 80 = 240 interpolated frames, frame-sharded): this rank's batches as
+    ``(clip, first_frame, stop_frame)`` with ``stop - first <= B`` - its contiguous block of the flattened (clip, frame) list,
+    exactly as ``walk()`` shards it (parallel.partition_frames), cut into calls of at most B frames.  Pure host logic, no rank
+    is special: tests/test_dist_cpu.py runs it for world = 8 over gloo."""
+    from stable_diffusion_videos_amd import parallel
+    counts = list(counts or CONFIG3["counts"])
+    plan = []
+    for ci, a, b in parallel.partition_frames(counts, world, rank):
+        for s in range(a, b, B):
+            plan.append((ci, s, min(s + B, b)))
+    return plan
+
+
+def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
+    """Self-check of the benchmarked configuration, OUTSIDE the clock: four frames of the last timed batch are generated again
+    in a 4-frame call (eager, so nothing of the big batch's captured graph is reused) and compared with what the big batch
+    returned - (a) with the tile selection the library makes for 8 samples, (b) with every igemm forced onto the 256 x 320 tile
+    the big batch runs.  (b) must be BIT-IDENTICAL: every output element sees the same sequence of MFMA k-steps whatever the
+    batch, the GroupNorm statistics are split by image size only, attention is per (sample, head).  (a) may differ in the
+    last place of a few pixels: the LayerNorm row statistics leave the producer GEMM as per-(N tile, wave column) partial sums
+    and the small batch picks other tiles (tests/test_bench_config_gpu.py) - tolerance 2 uint8 LSB."""
+    from stable_diffusion_videos_amd import hip
+    B = embeds.shape[0]
+    idx = sorted({0, max(B // 2 - 1, 0), B // 2, B - 1})
+    sel = torch.tensor(idx, device=embeds.device)
+    kw = dict(latents=noise[sel].contiguous(), text_embeddings=embeds[sel].contiguous(), height=size, width=size,
+              num_inference_steps=inference_steps, guidance_scale=7.5, eta=0.0, output_type="numpy_u8")
+    graphs, prev_tile = pipe.use_graphs, hip.FORCE_TILE
+    out = {"frames": idx, "vs": f"the same frames recomputed in a {len(idx)}-frame call (eager)", "tolerance_u8": 2}
+    try:
+        pipe.use_graphs = False
+        a = pipe(**kw)["images"]
+        hip.FORCE_TILE = 6
+        b = pipe(**kw)["images"]
+    finally:
+        pipe.use_graphs, hip.FORCE_TILE = graphs, prev_tile
+    ref = frames_u8[idx].astype(np.int32)
+    da, db = np.abs(a.astype(np.int32) - ref), np.abs(b.astype(np.int32) - ref)
+    out.update(max_abs_u8=int(da.max()), mean_abs_u8=round(float(da.mean()), 6),
+               max_abs_u8_same_tiles=int(db.max()), frames_differ=bool(np.abs(ref[0] - ref[-1]).mean() > 0.5))
+    out["ok"] = bool(out["max_abs_u8"] <= 2 and out["max_abs_u8_same_tiles"] == 0 and out["frames_differ"])
+    return out
+
+
+def short_pass(arch, size, B, dtype, inference_steps, steps=2):
+    """A short measured pass of another BASELINE config on this GPU (own pipeline, own warm-up batch, `steps` timed batches)."""
+    from stable_diffusion_videos_amd import StableDiffusionWalkPipeline
+    name = {"sd14": "CompVis/stable-diffusion-v1-4", "sd21": "stabilityai/stable-diffusion-2-1"}[arch]
+    pipe = StableDiffusionWalkPipeline.from_pretrained(name, arch=arch, fp8=dtype == "fp8").to(torch.device("cuda", torch.cuda.current_device()))
+    h = size // 8
+    T = np.linspace(0.0, 1.0, (steps + 1) * B)
+    gen = pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), T, B)
+
+    def one():
+        _, e, n = next(gen)
+        return pipe(latents=n, text_embeddings=e, height=size, width=size, num_inference_steps=inference_steps, guidance_scale=7.5,
+                    eta=0.0, output_type="numpy_u8")["images"]
+
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fps = steps * B / dt
+    res = {"value": round(fps, 4), "unit": "frames/s", "steps": steps, "warmup": 1, "batch_size": B, "ms_per_step": round(1e3 * dt / steps, 2),
+           "workload": f"{arch} walk, 2 prompts, {size}x{size}, {inference_steps} DDIM steps, CFG 7.5, {B} frames per call",
+           "dtype": "bf16" if dtype == "bf16" else "fp8 (e4m3 ResBlock convs, MX form) + bf16", "frames_shape": list(out.shape)}
+    if FLOP_PER_FRAME.get(arch) and inference_steps == 50:
+        ach = fps * FLOP_PER_FRAME[arch] / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "flop_per_frame": FLOP_PER_FRAME[arch]}
+    del pipe, gen
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 class EventProfiler:
@@ -351,13 +438,12 @@ def main():
         # BASELINE.json configs[2]: 4 prompts, [80, 80, 80] = 240 interpolated frames in TOTAL, frame-sharded over the ranks
         # (30 per rank on 8 GPUs): strong scaling.  Every rank takes its contiguous block of the flattened (clip, frame) list
         # exactly as walk() does and runs it in batches of at most B frames (one untimed warm-up batch first).
-        prompts, seeds, counts = ["a cat", "a dog", "a horse", "a cow"], [42, 1337, 2022, 4321], [80, 80, 80]
-        shares = parallel.partition_frames(counts, world, rank)
+        prompts, seeds, counts = CONFIG3["prompts"], CONFIG3["seeds"], CONFIG3["counts"]
         work = []
-        for ci, a, b in shares:
+        for ci, a, b in config3_plan(world, rank, B):
             T = np.linspace(0.0, 1.0, counts[ci])[a:b]
-            for _, embeds, noise in pipe.generate_inputs(prompts[ci], prompts[ci + 1], seeds[ci], seeds[ci + 1], (1, 4, h, h), T, B):
-                work.append((embeds, noise))
+            _, embeds, noise = next(pipe.generate_inputs(prompts[ci], prompts[ci + 1], seeds[ci], seeds[ci + 1], (1, 4, h, h), T, B))
+            work.append((embeds, noise))
         my_T = np.linspace(0.0, 1.0, B)
 
         def run(embeds, noise):
@@ -385,8 +471,11 @@ def main():
         my_T = T_all[rank * (args.steps + args.warmup) * B:(rank + 1) * (args.steps + args.warmup) * B]
         gen = pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), my_T, B)
 
+        last_in = [None]
+
         def one_step():
             _, embeds, noise = next(gen)
+            last_in[0] = (embeds, noise)
             out = pipe(latents=noise, text_embeddings=embeds, height=size, width=size,
                        num_inference_steps=args.inference_steps, guidance_scale=7.5, eta=0.0, output_type="numpy_u8")
             return out["images"]                               # uint8 NHWC frames on the host
@@ -407,10 +496,15 @@ def main():
                     f"BASELINE config 2 names 60 frames - this is the same walk with more frames, see `walk_60_frames` for the "
                     f"literal one), {size}x{size}, {args.inference_steps} DDIM steps, CFG 7.5")
         scaling = "weak"
+    rank_seconds = [round(elapsed, 4)]
     if world > 1:
+        # every rank's own time over the same barrier-to-barrier region: the line's `value` uses the MAX, the list shows a
+        # straggler (rank 0 does nothing the others do not inside the region; it builds the synthetic state dict before it)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        rank_seconds = [round(float(x.item()), 4) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
 
     fps = frames / elapsed
     flop_per_frame = FLOP_PER_FRAME.get(args.arch)
@@ -420,7 +514,7 @@ def main():
         "value": round(fps, 4), "unit": "frames/s", "n_gpus": world,
         "rccl_ranks": world if (world > 1 and torch.distributed.get_backend() == "nccl") else (1 if world == 1 else 0),
         "dist_backend": torch.distributed.get_backend() if world > 1 else None,
-        "steps": steps_done, "warmup": args.warmup,
+        "steps": steps_done, "warmup": args.warmup, "rank_seconds": rank_seconds,
         "ms_per_step": round(1e3 * elapsed / max(steps_done, 1), 2), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "fp8 (e4m3 ResBlock convs) + bf16", "data": "synthetic (seeded random-init SD weights, hash-tokenised prompts)",
         "config": {"workload": workload, "batch_size": B, "frames": frames, "parallelism": f"frame-sharded dp{world}",
@@ -483,6 +577,8 @@ def main():
                                                  "batch_size": 60, "includes": "as walk_60_frames, step graph already captured"}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
+        if args.config == 2 and not args.no_parity_check:
+            result["parity_check"] = parity_check(pipe, last_in[0][0], last_in[0][1], last, size, args.inference_steps)
         # host-side PNG encode rate (outside `value`; the reference pays it serially at :553)
         from PIL import Image
         import io
@@ -497,7 +593,27 @@ def main():
             except Exception as exc:  # the GPU number must still be reported
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {exc!r}"}
+        if (world == 1 and args.config == 2 and args.arch == "sd14" and args.dtype == "bf16" and size == 512 and
+                args.inference_steps == 50 and not args.no_other_configs):
+            # BASELINE configs 4 and 5 on this GPU, short passes with their own warm-up (the headline `value` above stays
+            # config 2 in bf16).  The bf16 pipeline's graphs and buffers go first.
+            import gc
+            pipe._graphs.clear()
+            del pipe, gen
+            gc.collect()
+            torch.cuda.empty_cache()
+            oc = {}
+            for key, kw in (("sd21_768", dict(arch="sd21", size=768, B=32, dtype="bf16")),
+                            ("fp8_mx", dict(arch="sd14", size=512, B=B, dtype="fp8"))):
+                try:
+                    oc[key] = short_pass(inference_steps=50, **kw)
+                except Exception as exc:  # the headline line must still be printed
+                    oc[key] = {"value": None, "error": repr(exc)}
+            result["other_configs"] = oc
         print(json.dumps(result), flush=True)
+        if result.get("parity_check") is not None and not result["parity_check"]["ok"]:
+            parallel.barrier()
+            raise SystemExit("bench.py: the parity self-check of the last batch failed: " + json.dumps(result["parity_check"]))
     parallel.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -120,6 +120,10 @@ typedef struct sdv_gemm_args {
      * re-reads a pixel's 128 bytes nine slabs in a row, so the 32 workgroups of an XCD keep their shifted windows inside the
      * 4 MiB L2 instead of re-fetching every tap from the fabric (profiles/round3_*).  -1 = the library's default. */
     int32_t k_order;
+    /* filled in by sdv_gemm_bf16: tile order of the persistent 8-wave workgroups.  0 = workgroup b takes tiles b, b + grid, ...
+     * of the XCD-aware raster; S > 0 = PANEL WALK: a workgroup takes whole M panels and walks tiles_n / S N tiles of each back
+     * to back (S workgroups share a panel), see sdv_gemm_set_walk.  Same tiles, same results - only the order changes. */
+    int32_t walk;
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
@@ -129,6 +133,15 @@ int sdv_gemm_stats_slots(const sdv_gemm_args* args);
  * first K slab prefetched behind the current tile's epilogue.  sdv_gemm_set_persistent(0) falls back to one workgroup per
  * tile (bit-identical results; for A/B timing in tools/).  Returns the previous setting. */
 int sdv_gemm_set_persistent(int on);
+/* > 0: at most n persistent workgroups per launch (default: one per CU).  Test / tools knob: with a small limit even a
+ * 32-tile problem WALKS tiles, so the tile-walk path (next tile's first K slab behind the epilogue) can be put under the
+ * oracle-based parity gates at sizes the CPU oracle finishes in seconds.  Returns the previous setting. */
+int sdv_gemm_set_grid_limit(int n);
+/* Tile order of the persistent workgroups (sdv_gemm_args.walk): 0 = strided raster (workgroup b: tiles b, b + grid, ...);
+ * S = 1 / 2 / 4: panel walk with S workgroups per M panel.  The walk is used only where it leaves every workgroup the same
+ * number of tiles (M panels divisible over the panel slots), otherwise the launch falls back to the strided order.
+ * Results are bit-identical either way.  Returns the previous setting. */
+int sdv_gemm_set_walk(int s);
 /* partial (sum, sumsq) [rows][slots][2] -> (mean, rstd) [rows][2] over C channels */
 int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, int32_t C, float eps, float* out, void* stream);
 

@@ -32,7 +32,15 @@
 #define SDV_BF16_ROT_AH 2
 #endif
 
+// GEGLU epilogue: 1 = the rearranged exact-erf GELU (sdv_common.h gelu_erf_fast_f, 11 + 2 VALU), 0 = the round-1 form (18 + 2) -
+// kept for A/B builds (tools/ubench/build_variant.py gelu0 -DSDV_GELU_FAST=0).
+#ifndef SDV_GELU_FAST
+#define SDV_GELU_FAST 1
+#endif
+
 namespace {
+
+SDV_DEVICE float geglu_gate_f(float x) { return SDV_GELU_FAST ? gelu_erf_fast_f(x) : gelu_erf_f(x); }
 
 // waves per SIMD the register allocator must leave room for: the 32-wide-K tiles are meant to run two workgroups
 // per CU (16 waves -> 4 per SIMD -> <= 128 VGPRs)
@@ -142,7 +150,26 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     // 5-12 % slower (profiles/round3_conv_k_order.txt), so the default stays tap-major
     const bool chan_major = CONV && p.k_order == 1 && p.mode != 0;
     auto setup_tile = [&](int vb) {
-        const int bz = vb / nblk;           // batch index (mode 4: the phase)
+        int bm, bn, bz;
+        if (PERSIST && p.walk > 0) {
+            // PANEL WALK (sdv_hip.h "walk"): a workgroup takes whole M panels and walks `tiles_n / S` N tiles of each back to back,
+            // so that from the second N tile on its X panel comes out of the L2 / Infinity Cache it has just been pulled through
+            // instead of HBM (the default order only shares a panel between CUs that miss on it at the same time).  XCD x owns a
+            // contiguous run of panels (neighbouring conv panels share their halo rows through that XCD's L2); inside it the
+            // G/8 workgroups form J = G/8/S panel slots of S workgroups, each workgroup one N range of the slot's panels.
+            const int G = (int)gridDim.x;
+            const int it = vb / G, b = vb - it * G;
+            const int S = p.walk, J = (G >> 3) / S, per = tiles_n / S;
+            const int xcd = b & 7, j = b >> 3;
+            const int slot = j / S, nsub = j - slot * S;
+            const int xq = tiles_m >> 3, xr = tiles_m & 7;
+            const int start = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+            const int kp = it / per;
+            bm = start + slot + kp * J;
+            bn = nsub * per + (it - kp * per);
+            bz = 0;
+        } else {
+        bz = vb / nblk;           // batch index (mode 4: the phase)
         const int lb = vb - bz * nblk;
         // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs; remap
         // (bijectively) so that each XCD - each private L2 - works on one contiguous run of tiles: neighbouring
@@ -164,8 +191,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             gcols = tiles_n - full * gn;
         }
         const int rr = tile_id - strip * strip_sz;
-        const int bm = rr / gcols;
-        const int bn = strip * gn + (rr - bm * gcols);
+        bm = rr / gcols;
+        bn = strip * gn + (rr - bm * gcols);
+        }
         const int m0 = bm * BM;
         const int n0 = bn * BN;
         a_m0 = m0;
@@ -850,7 +878,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = ((acc[nt][mt][4 * q + e] - ln_mu * svv[e]) * ar + bvv[e]) *
-                               gelu_erf_f((acc[nt][mt][4 * (q + 2) + e] - ln_mu * sgv[e]) * ar + bgv[e]);
+                               geglu_gate_f((acc[nt][mt][4 * (q + 2) + e] - ln_mu * sgv[e]) * ar + bgv[e]);
                     return;
                 }
                 const int nb = wcol0 + nt * 32 + 8 * q + 4 * lhi;
@@ -1149,7 +1177,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                             a += bias[nv + e];
                             gt += bias[nv + 16 + e];
                         }
-                        v[e] = a * gelu_erf_f(gt);
+                        v[e] = a * geglu_gate_f(gt);
                     }
                     uint2 o;
                     o.x = pack_bf16x2(v[0], v[1]);
@@ -1273,6 +1301,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
 
 constexpr int kDefaultConvKOrder = 0;   // sdv_gemm_args.k_order -1 resolves to this (tap-major; see profiles/round3_conv_k_order.txt)
 int g_persistent = 1;   // sdv_gemm_set_persistent(): A/B switch for tools/ (0 = one workgroup per tile, as in round 1)
+int g_grid_limit = 0;   // sdv_gemm_set_grid_limit(): > 0 caps the persistent grid (tests: make small problems WALK tiles)
+int g_walk = 0;         // sdv_gemm_set_walk(): 0 = strided tile order; S > 0 = panel walk, S workgroups per panel
 
 int current_device() {
     int dev = 0;
@@ -1312,9 +1342,20 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     SDV_REQUIRE(total < 0x7fffffffLL, "sdv_gemm_bf16: too many tiles");
     // (a ring tile's workgroup walks tiles only when every tile has at least NST K slabs: the stream runs NST-1 slabs ahead)
     const long long nkt = (long long)(a.K / BK) * (CONV ? (a.mode == 4 ? 4 : 9) : 1);
-    const bool walk = PERSIST && g_persistent && total > num_cus() && (NST == 2 || nkt >= NST);
-    dim3 grid((unsigned)(walk ? num_cus() : total), 1, 1);
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>), grid, dim3(WM * WN * 64), LDS, stream, a);
+    const int cus = g_grid_limit > 0 && g_grid_limit < num_cus() ? g_grid_limit : num_cus();
+    const bool walk = PERSIST && g_persistent && total > cus && (NST == 2 || nkt >= NST);
+    dim3 grid((unsigned)(walk ? cus : total), 1, 1);
+    // Panel walk (sdv_hip.h "walk"): only where every workgroup gets the same number of tiles - G/8/S panel slots per XCD, each
+    // XCD's share of the M panels a whole number of rounds over its slots - and there is more than one N tile to walk.
+    sdv_gemm_args aw = a;
+    aw.walk = 0;
+    if (walk && NST == 2 && g_walk > 0 && (a.batch <= 1) && a.mode != 4 && tiles_n >= 2 && (cus & 7) == 0) {
+        int S = g_walk;                                   // workgroups sharing a panel (each walks tiles_n / S N tiles of it)
+        while (S > 1 && (tiles_n % S != 0 || (cus >> 3) % S != 0)) S >>= 1;
+        const int J = (cus >> 3) / S;                     // panel slots per XCD
+        if (J > 0 && tiles_m % (8 * J) == 0) aw.walk = S;
+    }
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>), grid, dim3(WM * WN * 64), LDS, stream, aw);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
 }
@@ -1364,6 +1405,18 @@ extern "C" int sdv_gemm_stats_slots(const sdv_gemm_args* args) { return sdv_gemm
 extern "C" int sdv_gemm_set_persistent(int on) {
     const int prev = g_persistent;
     g_persistent = on ? 1 : 0;
+    return prev;
+}
+
+extern "C" int sdv_gemm_set_grid_limit(int n) {
+    const int prev = g_grid_limit;
+    g_grid_limit = n > 0 ? n : 0;
+    return prev;
+}
+
+extern "C" int sdv_gemm_set_walk(int s) {
+    const int prev = g_walk;
+    g_walk = s > 0 ? s : 0;
     return prev;
 }
 

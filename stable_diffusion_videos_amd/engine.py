@@ -397,15 +397,20 @@ class UNetEngine:
         self.num_steps = 0
         self.fp8_calibrated = False
 
-    def fp8_calibration(self, on: bool):
+    def fp8_calibration(self, on: bool, ok: bool = True, restore=None):
         """While on, every (eager) forward WIDENS the e4m3 activation scales of the ResBlock convs to cover what it sees
-        (running maximum); turning it off freezes them and marks the engine calibrated.  Host synchronising - never inside a
-        graph capture."""
+        (running maximum); turning it off freezes them and - when the run succeeded (``ok``) - marks the engine calibrated.
+        ``ok=False`` (the calibration run raised): the scales go back to ``restore`` (``fp8_scales()`` taken before the run)
+        and the engine stays uncalibrated.  Host synchronising - never inside a graph capture."""
         for r in self.res:
             if r.fp8:
                 r.calibrating = bool(on)
         if not on:
-            self.fp8_calibrated = True
+            if ok:
+                self.fp8_calibrated = True
+            elif restore is not None:
+                for r, (a, b) in zip([r for r in self.res if r.fp8], restore):
+                    r.sx1, r.sx2 = a, b
 
     def fp8_scales(self):
         return [(r.sx1, r.sx2) for r in self.res if r.fp8]

@@ -5,8 +5,9 @@ The reference writes its frames with ``torchvision.io.write_video(..., options={
 exist in this image, so this module produces the same KIND of stream - H.264, 4:2:0, 8 bit, every picture an IDR picture - with
 the one macroblock type that needs no entropy-coding tables: ``I_PCM`` (clause 7.3.5, mb_type 25 of an I slice), whose 384 sample
 bytes are carried verbatim.  That makes the video track LOSSLESS in YUV (libx264 at crf 10 is merely close to it) at 1.5 bytes per
-pixel (393 KB per 512 x 512 frame, about what crf 10 spends on noisy diffusion frames), and every conforming decoder - hardware ones
-included - plays it; what it gives up is compression, not compatibility.
+pixel (393 KB per 512 x 512 frame - UNCOMPRESSED, several times what an entropy-coded crf 10 stream takes; video.py falls back to
+Motion-JPEG above H264_PCM_MAX_BYTES), and every conforming decoder - hardware ones included - plays it; what it gives up is
+compression, not compatibility.
 
 Layout of what is written (all syntax elements in the order of clauses 7.3.2.1.1, 7.3.2.2, 7.3.3, 7.3.5 and Annex E):
   * SPS: profile_idc 66 (Baseline) with constraint_set0/1 flags, level from Table A-1 by picture size / macroblock rate / bit rate,

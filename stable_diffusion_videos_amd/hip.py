@@ -38,11 +38,11 @@ class GemmArgs(C.Structure):
         ("alpha_cols", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
         ("fp8", C.c_int32), ("out_mode", C.c_int32), ("out_f32", C.c_void_p), ("out_u8", C.c_void_p),
-        ("k_order", C.c_int32),
+        ("k_order", C.c_int32), ("walk", C.c_int32),
     ]
 
 
-ABI_VERSION = 7     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 8     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -51,6 +51,8 @@ _SIGNATURES = {
     "sdv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "sdv_gemm_stats_slots": (C.c_int, [C.POINTER(GemmArgs)]),
     "sdv_gemm_set_persistent": (C.c_int, [C.c_int]),
+    "sdv_gemm_set_grid_limit": (C.c_int, [C.c_int]),
+    "sdv_gemm_set_walk": (C.c_int, [C.c_int]),
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
@@ -142,6 +144,10 @@ FP8_MAX = 448.0
 _zero_pages = {}
 FP8_MX = int(os.environ.get("SDV_FP8_MX", "1"))            # developer knob for A/B: 0 = fp8 operands on the plain (bf16-rate) fp8 MFMA
 K_ORDER = int(os.environ.get("SDV_CONV_K_ORDER", "-1"))    # developer knob for A/B (tools/conv_order_ab.py); -1 = library default
+# Test / tools knob: launches that leave the tile to the cost model (tile=0) are forced onto this tile where it exists for them
+# (6 = the persistent 256 x 320 tile).  With it - and sdv_gemm_set_grid_limit - a 2-sample forward runs the SAME tile code paths as
+# the 256-sample benchmark forward, so they can be put under the oracle's block-wise absolute gate (tests/test_blockwise_gpu.py).
+FORCE_TILE = int(os.environ.get("SDV_FORCE_TILE", "0"))
 
 # Optional launch observer used by bench.py's roofline pass: called as hook(kind, info_dict, launch_fn).  The
 # hook must call launch_fn() itself (it may bracket it with HIP events).  None = no overhead.
@@ -224,6 +230,8 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
     a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, g["Hin"], g["Win"], g["Hout"], g["Wout"], g["circular"]
     a.epi, a.bias_mode, a.bias_step_stride = epi, (g["bias_mode"] if bias is not None else 0), g["bias_step_stride"]
     a.batch, a.tile, a.alpha, a.alpha_cols = batch, g["tile"], alpha, g["alpha_cols"]
+    if FORCE_TILE and not g["tile"] and not g["out_mode"] and epi < 3 and not (ln_stats is not None and g["ln_side"] == 2):
+        a.tile = FORCE_TILE
     if ln_stats is not None:
         a.ln_stats, a.ln_s, a.ln_side = _ptr(ln_stats, F32, "ln_stats"), _ptr(ln_s, F32, "ln_s"), g["ln_side"]
     partials = None

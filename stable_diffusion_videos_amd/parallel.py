@@ -23,6 +23,17 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def local_world_size() -> int:
+    """Ranks that share THIS host (torchrun's LOCAL_WORLD_SIZE; one node is all this path supports, so WORLD_SIZE otherwise)."""
+    return max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or "1"))
+
+
+def host_threads_per_rank() -> int:
+    """This rank's share of the host cores: every rank of an 8-GPU node runs its own PNG writer pool and its own torch CPU
+    thread pool - sized from ``os.cpu_count()`` each, 8 ranks would put 8 x (all cores) threads on one host."""
+    return max(1, (os.cpu_count() or 4) // local_world_size())
+
+
 def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     backend "nccl" is RCCL on ROCm.  Returns (rank, world_size, local_rank)."""
@@ -38,6 +49,9 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = os.environ.get("SDV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if ws > 1 and "OMP_NUM_THREADS" not in os.environ:
+            # one CPU thread pool per rank, each its share of the host - not N pools of cpu_count() threads
+            torch.set_num_threads(min(torch.get_num_threads(), host_threads_per_rank()))
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))

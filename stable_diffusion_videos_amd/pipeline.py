@@ -197,11 +197,15 @@ class StableDiffusionWalkPipeline:
             sched_kw = {}
             if model_dir is not None and (model_dir / "scheduler" / "scheduler_config.json").exists():
                 # a checkpoint directory decides its own scheduler, as diffusers' from_pretrained does (SD-v1: PNDMScheduler)
-                from .scheduler import SCHEDULERS
+                from .scheduler import SCHEDULERS, kwargs_from_config
                 sc = json.loads((model_dir / "scheduler" / "scheduler_config.json").read_text())
-                ptype = sc.get("prediction_type", "epsilon")
-                sched_cls = SCHEDULERS.get(sc.get("_class_name", "DDIMScheduler"), DDIMScheduler)
-                sched_kw = {k: sc[k] for k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule") if k in sc}
+                cname = sc.get("_class_name", "DDIMScheduler")
+                if cname not in SCHEDULERS:
+                    raise NotImplementedError(f"{model_dir}/scheduler: {cname} is not one of {sorted(SCHEDULERS)}")
+                sched_cls = SCHEDULERS[cname]
+                # every key the class acts on (set_alpha_to_one, skip_prk_steps, solver_order ...), unsupported options raise
+                sched_kw = kwargs_from_config(cname, sc)
+                ptype = sched_kw.pop("prediction_type", "epsilon")
             scheduler = sched_cls(prediction_type=ptype, **sched_kw)
         text_encoder = build_text_encoder(tcfg, model_dir, seed=synthetic_seed + 2)
         tokenizer = load_tokenizer(model_dir, tcfg)
@@ -321,7 +325,9 @@ class StableDiffusionWalkPipeline:
         ts = tuple(float(t) for t in self.scheduler.timesteps)
         if not ddim:
             eta = 0.0        # "eta is only used with the DDIMScheduler, it will be ignored for others" (:236, :404-409)
-        key = (type(self.scheduler).__name__, ts, float(eta), self.scheduler.config.prediction_type)
+        # (the whole config: two objects of one class with different betas / set_alpha_to_one / solver_order must not share a
+        #  coefficient table - and the captured graphs that bake in its pointer)
+        key = (type(self.scheduler).__name__, ts, float(eta), repr(sorted(vars(self.scheduler.config).items())))
         if key not in self._sched_cache:
             while len(self._sched_cache) >= 8:
                 gone = next(iter(self._sched_cache))
@@ -358,6 +364,7 @@ class StableDiffusionWalkPipeline:
         multistep = coefs.shape[1] == 16
         hist = torch.zeros((4,) + tuple(lat.shape), dtype=F32, device=self.device) if multistep else None
         xsave = torch.zeros_like(lat) if multistep else None
+        before = self.unet.fp8_scales()
         self.unet.fp8_calibration(True)
         try:
             for _ in range(nsteps):
@@ -367,9 +374,16 @@ class StableDiffusionWalkPipeline:
                 else:
                     hip.cfg_ddim_step(eps, lat, x2, coefs, step, None, guidance, cfg, lat.numel())
                 hip.step_counter_add(step, 1)
-        finally:
-            self.unet.fp8_calibration(False)
-        torch.cuda.synchronize(self.device)
+            torch.cuda.synchronize(self.device)
+        except BaseException:
+            # a pilot that died part-way (out of memory, a bad shape) must not leave half-widened scales behind and must not
+            # mark the engine calibrated: the next call runs the whole pilot again
+            self.unet.fp8_calibration(False, ok=False, restore=before)
+            raise
+        self.unet.fp8_calibration(False)
+        # the pilot's 2-sample cross-attention K / V^T buffers and workspaces are only kept when a 2-sample step is what runs next
+        if not any(k[1] == nimg for k in self._graphs):
+            self.unet.release(nimg)
 
     def _graph_entry(self, key: tuple, nimg: int, B: int, h: int, w: int, cfg: bool, guidance: float, coefs, eta_noise):
         """Static buffers + a captured hipGraph of ONE denoise step (UNet forward + CFG/DDIM update + step++)."""

@@ -179,13 +179,6 @@ class _TableScheduler:
     def _reset_state(self):
         self._i, self._hist, self._xsave, self._head = 0, [None] * 4, None, 0
 
-    def _index(self, timestep) -> int:
-        ts = self.timesteps.double()
-        idx = (ts == float(timestep)).nonzero()
-        if len(idx) == 0:
-            raise ValueError(f"timestep {timestep} is not in this scheduler's schedule")
-        return int(idx[0]) if len(idx) == 1 else None
-
     def scale_model_input(self, sample, timestep=None):
         return sample
 
@@ -197,6 +190,9 @@ class _TableScheduler:
         i = self._i
         if i >= rows.shape[0]:
             raise RuntimeError("step() called more often than set_timesteps() scheduled")
+        if timestep is not None and abs(float(timestep) - float(self.timesteps[i])) > 1e-3:
+            raise ValueError(f"step() number {i} was given timestep {float(timestep)}, the schedule has {float(self.timesteps[i])} "
+                             "there: the table-driven schedulers must be stepped in schedule order (as the reference does, :412-426)")
         a, c, w0, w1, w2, w3, u, v, s_in, s_noise, flags, head = (float(x) for x in rows[i, :12].double())
         flags, head = int(flags), int(head)
         x = sample.to(torch.float32)
@@ -412,17 +408,55 @@ SCHEDULERS = {c.__name__: c for c in (DDIMScheduler, PNDMScheduler, LMSDiscreteS
                                       EulerAncestralDiscreteScheduler, DPMSolverMultistepScheduler)}
 
 
+# Config keys each class honours (everything its __init__ acts on).  A foreign scheduler's config / a checkpoint's
+# scheduler_config.json is forwarded key by key, so that the unsupported-value guards of the constructors stay active
+# (diffusers' PNDMScheduler defaults to skip_prk_steps=False, its DDIMScheduler to set_alpha_to_one=True - ADVICE r3: both used to
+# be dropped and silently replaced by this module's defaults).
+_COMMON_KEYS = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "steps_offset")
+_CONFIG_KEYS = {
+    "DDIMScheduler": _COMMON_KEYS + ("set_alpha_to_one",),          # clip_sample: forced off, as the reference does (:99-110)
+    "PNDMScheduler": _COMMON_KEYS + ("skip_prk_steps", "set_alpha_to_one"),
+    "LMSDiscreteScheduler": _COMMON_KEYS,
+    "EulerDiscreteScheduler": _COMMON_KEYS,
+    "EulerAncestralDiscreteScheduler": _COMMON_KEYS,
+    "DPMSolverMultistepScheduler": _COMMON_KEYS + ("solver_order", "algorithm_type", "solver_type", "lower_order_final"),
+}
+# recognised diffusers options that change the arithmetic and are NOT implemented: anything but the listed "off" value raises
+_UNSUPPORTED_KEYS = {"trained_betas": (None,), "thresholding": (False, None), "use_karras_sigmas": (False, None),
+                     "use_exponential_sigmas": (False, None), "use_beta_sigmas": (False, None), "use_lu_lambdas": (False, None),
+                     "rescale_betas_zero_snr": (False, None), "euler_at_final": (False, None),
+                     "variance_type": (None, "fixed_small"), "interpolation_type": (None, "linear"),
+                     "final_sigmas_type": (None, "zero"), "use_flow_sigmas": (False, None),
+                     "timestep_type": (None, "discrete")}
+# timestep_spacing: each class implements the spacing its diffusers namesake defaults to
+_SPACING = {"DDIMScheduler": "leading", "PNDMScheduler": "leading", "LMSDiscreteScheduler": "linspace",
+            "EulerDiscreteScheduler": "linspace", "EulerAncestralDiscreteScheduler": "linspace",
+            "DPMSolverMultistepScheduler": "linspace"}
+
+
+def kwargs_from_config(class_name: str, cfg) -> dict:
+    """Constructor keywords of ``SCHEDULERS[class_name]`` from a diffusers-style config (mapping or attribute object)."""
+    has = (lambda k: k in cfg) if isinstance(cfg, dict) else (lambda k: hasattr(cfg, k))
+    get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+    for k, ok in _UNSUPPORTED_KEYS.items():
+        if has(k) and get(k) not in ok:
+            raise NotImplementedError(f"{class_name}: config option {k}={get(k)!r} is not implemented by the table-driven "
+                                      f"schedulers (supported: {ok[0]!r})")
+    if has("timestep_spacing") and get("timestep_spacing") not in (None, _SPACING[class_name]):
+        raise NotImplementedError(f"{class_name}: timestep_spacing={get('timestep_spacing')!r} is not implemented "
+                                  f"(this class spaces its timesteps {_SPACING[class_name]!r}, its diffusers default)")
+    return {k: get(k) for k in _CONFIG_KEYS[class_name] if has(k)}
+
+
 def adopt(scheduler):
     """A scheduler object of THIS module is returned as it is; a foreign one with a known class name (a diffusers scheduler
-    handed to ``from_pretrained(scheduler=...)``, examples/make_music_video.py:15) is rebuilt here from its config."""
+    handed to ``from_pretrained(scheduler=...)``, examples/make_music_video.py:15) is rebuilt here from its config - every key
+    the class acts on is carried over, recognised-but-unsupported options raise."""
     if isinstance(scheduler, (DDIMScheduler, _TableScheduler)):
         return scheduler
-    cls = SCHEDULERS.get(type(scheduler).__name__)
+    name = type(scheduler).__name__
+    cls = SCHEDULERS.get(name)
     if cls is None:
-        raise NotImplementedError(f"{type(scheduler).__name__}: not one of the schedulers the reference accepts "
+        raise NotImplementedError(f"{name}: not one of the schedulers the reference accepts "
                                   f"(stable_diffusion_pipeline.py:71-78): {sorted(SCHEDULERS)}")
-    cfg = getattr(scheduler, "config", None)
-    get = (lambda k, d: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d: getattr(cfg, k, d))
-    kw = {k: get(k, d) for k, d in (("num_train_timesteps", 1000), ("beta_start", 0.00085), ("beta_end", 0.012),
-                                    ("beta_schedule", "scaled_linear"), ("prediction_type", "epsilon"))}
-    return cls(**kw)
+    return cls(**kwargs_from_config(name, getattr(scheduler, "config", None) or {}))

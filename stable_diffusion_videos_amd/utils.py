@@ -58,7 +58,11 @@ class FrameWriter:
     releases the GIL, so threads scale across the host cores."""
 
     def __init__(self, workers: Optional[int] = None):
-        workers = workers or int(os.environ.get("SDV_WRITER_THREADS", max(2, (os.cpu_count() or 4) - 1)))
+        # this rank's share of the host cores, minus the thread that drives the GPU (8 ranks x (cpu_count - 1) PNG threads on one
+        # host would oversubscribe it eight-fold)
+        from .parallel import host_threads_per_rank
+        workers = workers or int(os.environ.get("SDV_WRITER_THREADS", max(2, host_threads_per_rank() - 1)))
+        self.workers = workers
         self.pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="sdv-png")
         self.pending: List[Future] = []
 

@@ -30,6 +30,10 @@ logger = logging.getLogger("stable_diffusion_videos_amd")
 # Codec of the dependency-free writer (env SDV_VIDEO_CODEC overrides): "h264" = the reference's codec family, lossless intra
 # pictures (h264.py, 1.5 bytes per pixel); "mjpeg" = JPEG quality 95 frames (~3x smaller, not playable in browsers).
 DEFAULT_CODEC = "h264"
+# The I_PCM H.264 track is UNCOMPRESSED (1.5 bytes per pixel: 0.39 MB per 512 x 512 frame, 6.3 MB per upsampled 2048 x 2048 frame,
+# several times what libx264 crf 10 writes): above this many bytes of video the dependency-free writer falls back to Motion-JPEG
+# unless SDV_VIDEO_CODEC asks for h264 explicitly (long or upsampled walks produced multi-GB mp4 files).
+H264_PCM_MAX_BYTES = int(os.environ.get("SDV_H264_PCM_MAX_BYTES", str(1 << 30)))
 
 
 def _box(kind: bytes, payload: bytes) -> bytes:
@@ -219,6 +223,15 @@ def make_video_pyav(frames_or_frame_dir: Union[str, Path, torch.Tensor] = "./ima
     if codec not in ("h264", "mjpeg"):
         raise ValueError(f"SDV_VIDEO_CODEC={codec!r}: expected 'h264' or 'mjpeg'")
     h, w = frames[0].shape[:2]
+    if codec == "h264":
+        est = len(frames) * (w * h * 3 // 2)
+        if est > H264_PCM_MAX_BYTES and not os.environ.get("SDV_VIDEO_CODEC"):
+            logger.warning("%d frames of %dx%d as uncompressed I_PCM H.264 would be %.1f GB: writing Motion-JPEG instead "
+                           "(set SDV_VIDEO_CODEC=h264 to force, SDV_H264_PCM_MAX_BYTES to move the limit)", len(frames), w, h, est / 1e9)
+            codec = "mjpeg"
+        else:
+            logger.info("H.264 I_PCM video track: %d frames of %dx%d = %.1f MB (uncompressed, 1.5 bytes per pixel)",
+                        len(frames), w, h, est / 1e6)
     if codec == "h264" and (h % 2 or w % 2):
         logger.warning("odd frame size %dx%d: yuv420p needs even sizes, writing Motion-JPEG instead", w, h)
         codec = "mjpeg"

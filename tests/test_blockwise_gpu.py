@@ -103,6 +103,31 @@ def test_sd_unet_blocks(hip, dev, arch):
     assert e2e <= bw.end_to_end_bound(floor)
 
 
+def test_sd14_unet_blocks_at_the_benchmark_geometry(hip, dev):
+    """The SD-v1-4 UNet on the BENCHMARK's geometry - 64 x 64 latent, 4096-token self-attention - with the kernels the 256-sample
+    benchmark forward runs: every igemm forced onto the 256 x 320 tile (``hip.FORCE_TILE``; at 2 samples the cost model would
+    pick the 4-wave tiles) and the persistent grid capped at 8 workgroups (``sdv_gemm_set_grid_limit``), so that every launch
+    WALKS tiles (next tile's first K slab behind the epilogue); the 32^2 -> 64^2 up-conv in phase form on that tile; the two-tile
+    dh-40 flash instance (Lq = 4096).  Same absolute, rounding-count bounds as above (~25 s of oracle time)."""
+    from stable_diffusion_videos_amd import config as cfgs
+    c = cfgs.sd14_unet()
+    oracle, engine = unet_pair(c, dev)
+    x, ctx = _io(c, 2, 64, 6)
+    lib = hip.load()
+    prev_limit, prev_tile = lib.sdv_gemm_set_grid_limit(8), hip.FORCE_TILE
+    hip.FORCE_TILE = 6
+    try:
+        recs, _ = _record_unet(engine, x, ctx, [981, 961], 0, dev)
+    finally:
+        hip.FORCE_TILE = prev_tile
+        lib.sdv_gemm_set_grid_limit(prev_limit)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    rows = bw.compare(oracle, [r for r in recs if r["kind"] != "transformer"], timestep=981, ctx=ctx)
+    _table("sd14 UNet, 64x64 latent, 256x320 persistent tile", rows)
+    assert len(rows) == 1 + 22 + 16 * 5 + 3 + 3 + 1
+    _gate(rows)
+
+
 @pytest.mark.parametrize("arch", ["tiny", "sd"])
 def test_vae_blocks(hip, dev, arch):
     from stable_diffusion_videos_amd import config as cfgs

@@ -660,6 +660,20 @@ def test_slerp_matches_reference_golden(hip, dev):
             tol = 2.0 * float(np.spacing(np.float32(gold.abs().max().item())))
             err = float((out[i] - gold).abs().max())
             assert err <= tol, (name, t, err, tol)
+    # fp16 in -> fp16 out, the reference's own fp16 behaviour (its numpy round trip reduces dot and the norms in float16,
+    # utils.py:45-61): the HIP path takes the SAME fp16 endpoints (exact in fp32), interpolates in fp32 and is compared with the
+    # reference's fp16 frames.  Tolerance, stated: one float16 ulp of the frame's largest element (1.95e-3 at |x| < 4) - half an
+    # ulp is the reference's own output rounding, the rest its float16 products and float16 dot (an fp32 / fp64 evaluation of
+    # the same formula sits 1.5e-3 ... 1.8e-3 from the golden frames, measured on the CPU); the endpoints t = 0 / 1 are exact.
+    d = np.load(GOLDEN / "slerp_seed7_8_fp16.npz")
+    v0, v1 = torch.from_numpy(d["v0"].astype(np.float32)).to(dev), torch.from_numpy(d["v1"].astype(np.float32)).to(dev)
+    stats = hip.slerp_stats(v0.contiguous(), v1.contiguous())
+    out = hip.slerp_batch(v0, v1, stats, torch.tensor(d["ts"], dtype=F32, device=dev), C_=1, HW=v0.numel(), to_hwc=False)
+    for i, t in enumerate(d["ts"]):
+        gold = torch.from_numpy(d[f"t{int(t * 100):03d}"].astype(np.float32)).to(dev).flatten()
+        err = float((out[i] - gold).abs().max())
+        tol = 0.0 if t in (0.0, 1.0) else float(np.spacing(np.float16(gold.abs().max().item())))
+        assert err <= tol, ("slerp_seed7_8_fp16", t, err, tol)
     # NHWC output layout + public slerp() helper
     from stable_diffusion_videos_amd.utils import slerp
     d = np.load(GOLDEN / "slerp_seed42_1337_fp32.npz")

@@ -134,3 +134,44 @@ def test_checkpoint_directory_picks_its_own_scheduler(tmp_path):
     assert isinstance(pipe.scheduler, P.PNDMScheduler)
     pipe.scheduler.set_timesteps(50)
     assert pipe.scheduler.timesteps[:4].tolist() == [981, 961, 961, 941] and len(pipe.scheduler.timesteps) == 51
+
+
+def test_adopt_forwards_every_config_key_and_keeps_the_guards_active():
+    """adopt() used to rebuild a foreign scheduler from five keys only, so diffusers' own defaults -
+    DDIMScheduler(set_alpha_to_one=True), PNDMScheduler(skip_prk_steps=False) - were silently replaced by this module's."""
+    def foreign(name, **cfg):
+        obj = type(name, (), {})()
+        obj.config = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", **cfg)
+        return obj
+
+    d1 = P.adopt(foreign("DDIMScheduler", set_alpha_to_one=True, steps_offset=0, clip_sample=True))
+    d0 = P.adopt(foreign("DDIMScheduler", set_alpha_to_one=False))
+    assert float(d1.final_alpha_cumprod) == 1.0 and float(d0.final_alpha_cumprod) == float(d0.alphas_cumprod[0])
+    assert d1.config.steps_offset == 0 and d1.config.clip_sample is False          # clip_sample is forced off (:99-110)
+    d1.set_timesteps(50)
+    d0.set_timesteps(50)
+    assert not torch.allclose(d1.coefficient_table(0.0)[-1], d0.coefficient_table(0.0)[-1])       # the last step differs
+    with pytest.raises(NotImplementedError, match="Runge-Kutta"):
+        P.adopt(foreign("PNDMScheduler", skip_prk_steps=False))                      # diffusers' default PNDM
+    assert P.adopt(foreign("PNDMScheduler", skip_prk_steps=True, set_alpha_to_one=True)).final_alpha_cumprod == 1.0
+    dp = P.adopt(foreign("DPMSolverMultistepScheduler", solver_order=1, lower_order_final=False, prediction_type="v_prediction"))
+    assert dp.config.solver_order == 1 and dp.config.lower_order_final is False and dp.config.prediction_type == "v_prediction"
+    with pytest.raises(NotImplementedError):
+        P.adopt(foreign("DPMSolverMultistepScheduler", algorithm_type="sde-dpmsolver++"))
+    for bad in (dict(use_karras_sigmas=True), dict(thresholding=True), dict(trained_betas=[0.1, 0.2]),
+                dict(rescale_betas_zero_snr=True), dict(timestep_spacing="trailing")):
+        with pytest.raises(NotImplementedError, match="not implemented"):
+            P.adopt(foreign("EulerDiscreteScheduler", **bad))
+    assert isinstance(P.adopt(foreign("EulerDiscreteScheduler", use_karras_sigmas=False, timestep_spacing="linspace")),
+                      P.EulerDiscreteScheduler)
+
+
+def test_table_schedulers_refuse_out_of_order_steps():
+    s = P.PNDMScheduler()
+    s.set_timesteps(5)
+    x = torch.zeros(1, 4, 2, 2)
+    ts = [int(t) for t in s.timesteps]
+    x = s.step(torch.zeros_like(x), ts[0], x).prev_sample
+    x = s.step(torch.zeros_like(x), ts[1], x).prev_sample
+    with pytest.raises(ValueError, match="schedule order"):
+        s.step(torch.zeros_like(x), ts[4], x)
