@@ -172,9 +172,9 @@ def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
     in a 4-frame call (eager, so nothing of the big batch's captured graph is reused) and compared with what the big batch
     returned - (a) with the tile selection the library makes for 8 samples, (b) with every igemm forced onto the 256 x 320 tile
     the big batch runs.  (b) must be BIT-IDENTICAL: every output element sees the same sequence of MFMA k-steps whatever the
-    batch, the GroupNorm statistics are split by image size only, attention is per (sample, head).  (a) may differ in the
-    last place of a few pixels: the LayerNorm row statistics leave the producer GEMM as per-(N tile, wave column) partial sums
-    and the small batch picks other tiles (tests/test_bench_config_gpu.py) - tolerance 2 uint8 LSB."""
+    batch, the GroupNorm statistics are split by image size only, attention is per (sample, head).  (a) is a second, independent
+    realisation of the bf16 roundings (other tiles -> other partial-sum groupings of the LayerNorm row statistics -> a flipped
+    rounding early on, tests/test_bench_config_gpu.py): it must sit where two bf16 realisations sit, PSNR >= 37 dB."""
     from stable_diffusion_videos_amd import hip
     B = embeds.shape[0]
     idx = sorted({0, max(B // 2 - 1, 0), B // 2, B - 1})
@@ -182,7 +182,7 @@ def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
     kw = dict(latents=noise[sel].contiguous(), text_embeddings=embeds[sel].contiguous(), height=size, width=size,
               num_inference_steps=inference_steps, guidance_scale=7.5, eta=0.0, output_type="numpy_u8")
     graphs, prev_tile = pipe.use_graphs, hip.FORCE_TILE
-    out = {"frames": idx, "vs": f"the same frames recomputed in a {len(idx)}-frame call (eager)", "tolerance_u8": 2}
+    out = {"frames": idx, "vs": f"the same frames recomputed in a {len(idx)}-frame call (eager)", "min_psnr_db": 37.0}
     try:
         pipe.use_graphs = False
         a = pipe(**kw)["images"]
@@ -192,9 +192,11 @@ def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
         pipe.use_graphs, hip.FORCE_TILE = graphs, prev_tile
     ref = frames_u8[idx].astype(np.int32)
     da, db = np.abs(a.astype(np.int32) - ref), np.abs(b.astype(np.int32) - ref)
-    out.update(max_abs_u8=int(da.max()), mean_abs_u8=round(float(da.mean()), 6),
-               max_abs_u8_same_tiles=int(db.max()), frames_differ=bool(np.abs(ref[0] - ref[-1]).mean() > 0.5))
-    out["ok"] = bool(out["max_abs_u8"] <= 2 and out["max_abs_u8_same_tiles"] == 0 and out["frames_differ"])
+    mse = float((da.astype(np.float64) ** 2).mean())
+    out.update(max_abs_u8_same_tiles=int(db.max()), max_abs_u8=int(da.max()), mean_abs_u8=round(float(da.mean()), 4),
+               psnr_db=round(10.0 * float(np.log10(255.0 ** 2 / max(mse, 1e-12))), 2),
+               frames_differ=bool(np.abs(ref[0] - ref[-1]).mean() > 0.5))
+    out["ok"] = bool(out["max_abs_u8_same_tiles"] == 0 and out["psnr_db"] >= out["min_psnr_db"] and out["frames_differ"])
     return out
 
 

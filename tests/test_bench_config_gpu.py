@@ -5,13 +5,18 @@ The reference pushes whatever ``batch_size`` the caller gives through one ``__ca
 (/root/reference/stable_diffusion_videos/stable_diffusion_pipeline.py:472, :538-548), so a frame must not depend on the batch it
 was generated in.  The CPU oracle cannot run 128 frames; what can be checked at this size:
 
-* frames {0, 63, 64, 127} of a 128-frame call against the SAME frames generated in a 4-frame call (same embeddings, same noise).
-  NOT bit-identical by construction, and the gate says by how much: every GEMM / conv / attention element sees the same sequence
-  of MFMA k-steps whatever tile the cost model picks (all tiles walk K in the same 64-wide slabs), and the GroupNorm statistics
-  are split by image size only - but the LayerNorm row statistics leave the producer GEMM as per-(N tile, wave column) partial
-  sums, and the cost model picks the 128 x 128 tile at M = 32 768 rows and the 256 x 320 tile at M = 1 048 576: different
-  partial-sum groupings move (mean, rstd) in the last fp32 bits, which flips a bf16 rounding here and there.  Gate: uint8
-  max-abs <= 2, mean-abs <= 0.02 (measured value in the report);
+* frames {0, 63, 64, 127} of a 128-frame call against the SAME frames generated in a 4-frame call (same embeddings, same noise)
+  WITH THE SAME TILES (``hip.FORCE_TILE = 6``: the 4-frame call runs the 256 x 320 tile the 128-frame call picks by itself):
+  **bit-identical**.  Every GEMM / conv / attention element sees the same sequence of MFMA k-steps whatever the batch, the
+  GroupNorm statistics are split by image size only, attention is per (sample, head), and with the same tile the LayerNorm
+  row statistics leave the producer GEMM in the same per-(N tile, wave column) partial sums - so nothing may depend on where
+  in a 1 048 576-row tensor a frame sits.  This is the check that the 64-bit addressing of the big batch is right;
+* the same comparison with the tiles the cost model picks for 8 samples (128 x 128 at M = 32 768 rows): NOT bit-identical and
+  not close to it either - other partial-sum groupings move (mean, rstd) of the LayerNorm rows in their last fp32 bits, that
+  flips a bf16 rounding here and there in the first transformer block, and from there on the two runs are two independent
+  realisations of the bf16 roundings (DESIGN (c): a difference delta becomes sqrt(delta * ulp) at the next rounding).  Measured:
+  uint8 mean-abs 1.9 / max-abs 17 after 2 of 50 steps (the decoded image is still mostly noise), i.e. 40.7 dB between the two
+  - the distance each of them has to the fp32 oracle (41.7 dB).  Gate: PSNR >= 37 dB (3 dB under two independent realisations);
 * frames 0 and 127 of the 128-frame call against the fp32 CPU oracle, the gate of ``test_sd14_full_size_two_steps`` (>= 39 dB);
 * one 128-frame VAE decode against 4-frame decodes of the same latents: bit-identical (no statistic depends on the batch).
 """
@@ -46,11 +51,22 @@ def test_batch128_frames_match_batch4_and_the_oracle(hip, dev):
     big = pipe(latents=noise, text_embeddings=embeds, **kw)["images"]
     assert big.shape == (B, 512, 512, 3) and big.dtype == np.uint8
     idx = torch.tensor(PICK, device=embeds.device)
-    small = pipe(latents=noise[idx].contiguous(), text_embeddings=embeds[idx].contiguous(), **kw)["images"]
+    skw = dict(latents=noise[idx].contiguous(), text_embeddings=embeds[idx].contiguous(), **kw)
+    pipe.use_graphs = False          # (eager: the two 4-frame runs below differ only in a host-side knob a captured graph would freeze)
+    hip.FORCE_TILE = 6
+    try:
+        same_tiles = pipe(**skw)["images"]
+    finally:
+        hip.FORCE_TILE = 0
+    small = pipe(**skw)["images"]
+    pipe.use_graphs = True
+    d0 = np.abs(big[PICK].astype(int) - same_tiles.astype(int))
     d = np.abs(big[PICK].astype(int) - small.astype(int))
-    report(f"batch 128 vs batch 4, SD-1.4 512x512, 2 steps, frames {PICK}: uint8 max-abs {d.max()}, mean-abs {d.mean():.5f}, "
-           f"pixels that differ {float((d > 0).mean()) * 100:.3f} %")
-    assert d.max() <= 2 and d.mean() <= 0.02
+    p_small = psnr(torch.from_numpy(big[PICK].astype(np.float32)), torch.from_numpy(small.astype(np.float32)), peak=255.0)
+    report(f"batch 128 vs batch 4, SD-1.4 512x512, 2 steps, frames {PICK}: SAME tiles uint8 max-abs {d0.max()} (must be 0); the "
+           f"cost model's tiles: max-abs {d.max()}, mean-abs {d.mean():.3f}, {p_small:.1f} dB between the two bf16 realisations")
+    assert d0.max() == 0
+    assert p_small >= 37.0
     # distinct frames really are distinct (a batch-index bug that returned one frame 128 times would pass the line above)
     assert np.abs(big[0].astype(int) - big[127].astype(int)).mean() > 1.0
     # the two end frames against the CPU oracle
