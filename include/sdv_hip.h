@@ -124,6 +124,14 @@ typedef struct sdv_gemm_args {
      * of the XCD-aware raster; S > 0 = PANEL WALK: a workgroup takes whole M panels and walks tiles_n / S N tiles of each back
      * to back (S workgroups share a panel), see sdv_gemm_set_walk.  Same tiles, same results - only the order changes. */
     int32_t walk;
+    /* GroupNorm statistics out of the producing epilogue (ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out: the
+     * reference's nn.GroupNorm reads the tensor once for the statistics and once to normalise it; here the first read is gone).
+     * gn_out != NULL: fp32 [batch * M / 32][2][gn_ld] - for every block of 32 output rows and every output column the (sum, sumsq)
+     * of the bf16 values the tile stores (one writer per entry: deterministic).  mode 4: block index = phase * (M / 32) + m / 32.
+     * Needs epi 0, bf16 output, no fold / fp8 / out_mode, M % 32 == 0, 16-byte aligned operands (the row-major store sequence).
+     * sdv_groupnorm_finalize turns the blocks of an image (and the channels of a group) into sdv_groupnorm_apply's partials. */
+    float* gn_out;
+    int32_t gn_ld;
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
@@ -174,6 +182,14 @@ int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, int32_t ld, v
  *   stats: partial (sum, sumsq) per (image, split, group) -> `partials` [nimg][splits][groups][2]
  *   apply: finalises mean/rstd from the partials and writes bf16 y = act((x-mean)*rstd*g + b)
  * ------------------------------------------------------------------------------------------ */
+/* GroupNorm statistics from the producer's epilogue: P1 (and P2 for a channel concat [x, skip]) are sdv_gemm_args.gn_out arrays
+ * [blocks][2][ld] of (sum, sumsq) per 32-row block and channel; image i owns blocks [i * bpi, (i + 1) * bpi) of each of `nrep`
+ * repetitions `rep_stride` blocks apart (mode 4 producers: 4 phases).  Writes partials [nimg][splits][groups][2] (an image's
+ * blocks cut into `splits` <= 64 ranges, one workgroup each) for sdv_groupnorm_apply with the same `splits` - the statistics
+ * pass over the tensor (sdv_groupnorm_stats) is not needed then. */
+int sdv_groupnorm_finalize(const float* P1, int32_t C1, int32_t ld1, int32_t bpi1, int32_t nrep1, int64_t rep_stride1,
+                           const float* P2, int32_t C2, int32_t ld2, int32_t bpi2, int32_t nrep2, int64_t rep_stride2,
+                           int32_t nimg, int32_t groups, int32_t splits, float* partials, void* stream);
 int sdv_groupnorm_stats(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
                         int32_t HW, int32_t groups, int32_t splits, float* partials, void* stream);
 int sdv_groupnorm_apply(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,

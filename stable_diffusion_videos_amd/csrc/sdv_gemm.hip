@@ -1009,8 +1009,67 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         }
                     }
                 };
+                // GroupNorm statistics of the tile as STORED (sdv_hip.h "gn_out"): per 32-row block and output column the (sum, sumsq)
+                // of the bf16 values, so that the consumer's GroupNorm needs no statistics pass over the tensor.  In the row-major
+                // phase a lane holds 8 columns of one row per item; the rows of a pass sit in the OTHER lanes and items, so the 8
+                // per-lane values of a statistic are reduced across the lanes that share a column group with a transposing
+                // butterfly: v_permlane32_swap / v_permlane16_swap fold lane bits 5 and 4 and halve the number of live values each
+                // (both results of a swap are used), row_ror DPP adds fold the lane bits left inside a row of 16.  Afterwards lane
+                // (rho0, rho1, column group cj) holds 2 consecutive columns of the statistic: one 8-byte store.
+                constexpr bool GN_OK = FEAT == 0 && (MODE == 0 || MODE == 1 || MODE == 4);
+                const bool gn_on = GN_OK && p.gn_out != nullptr;
+                // The summation tree of a (32-row block, column) entry is the SAME whatever tile and pass width produced it - row bits
+                // 4, 3 (the items: rows r, r+16 first, then r+8), then 2, 1, 0 (the lanes) - so the statistics of a tensor do not
+                // depend on the tile the cost model picked for its producer (batch size, CFG-shared prefix ...).
+                auto gn_reduce_store = [&](int pi, const u32x4_t* pk) {
+                    const int cpo = p_oc(pi) >> 3;                                  // lanes per row of the pass: 8 or 4
+                    const int row_first = m0 + wm * TM * 32 + p_mt(pi) * 32;
+                    const int cj = lane_e & 15, c2 = ((lane_e >> 3) & 2) | (lane_e >> 5);      // c2 = 2 * rho0 + rho1
+                    const int col = p_col0(pi) + cj * 8 + 2 * c2;
+                    const bool live = row_first < p.M && cj < cpo && col < ncols_out;
+                    const long long rb = bz * (long long)(p.M >> 5) + (row_first >> 5);
+                    // one statistic at a time (8 values -> 4 -> 2 per lane): half the live registers of doing both together
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        float x[8];
+#pragma unroll
+                        for (int h = 0; h < 4; ++h)
+#pragma unroll
+                            for (int o = 0; o < 2; ++o) {
+                                auto el = [&](int it) { return o ? __uint_as_float(pk[it][h] & 0xffff0000u) : __uint_as_float(pk[it][h] << 16); };
+                                float r;
+                                if (n_iters(pi) >= 4) {            // rows r, r + 8, r + 16, r + 24 of this lane's column
+                                    const float g0 = el(0), g1 = el(1), g2 = el(2), g3 = el(3);
+                                    r = st ? __builtin_fmaf(g2, g2, g0 * g0) + __builtin_fmaf(g3, g3, g1 * g1) : (g0 + g2) + (g1 + g3);
+                                } else {                            // rows r, r + 16
+                                    const float g0 = el(0), g1 = el(1);
+                                    r = st ? __builtin_fmaf(g1, g1, g0 * g0) : g0 + g1;
+                                }
+                                x[2 * h + o] = r;
+                            }
+                        // v[4 k + c] = x[2 c + k]: after the two swaps lane (rho0, rho1) holds columns 2 c2, 2 c2 + 1 of its group
+                        float w[4], u[2];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int j0 = 2 * i, j1 = 2 * i + 1;                   // v indices; v[j] = x[2 * (j & 3) + (j >> 2)]
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[2 * (j0 & 3) + (j0 >> 2)]),
+                                                                            __float_as_uint(x[2 * (j1 & 3) + (j1 >> 2)]), false, false);
+                            w[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * k]), __float_as_uint(w[2 * k + 1]), false, false);
+                            u[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                            u[k] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(u[k]), 0x128, 0xf, 0xf, false));       // row_ror:8
+                            if (cpo == 4)
+                                u[k] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(u[k]), 0x124, 0xf, 0xf, false));   // row_ror:4
+                        }
+                        if (live) *(float2*)(p.gn_out + (rb * 2 + st) * p.gn_ld + col) = make_float2(u[0], u[1]);
+                    }
+                };
                 // phase 2b: residual, activation, bf16, one 16-byte store per item (+ the row statistics of the stored values)
                 auto finish = [&](int pi) {
+                    u32x4_t gpk[MAXIT];      // the packed bf16 values of this pass's items (the store data, kept for the statistics)
 #pragma unroll
                     for (int it = 0; it < MAXIT; ++it) {
                         if (it >= n_iters(pi)) continue;
@@ -1059,6 +1118,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         // epi_race_diag.py: the stored dword held the next item's column index).  The compiler's hazard table
                         // has no wait state for a store with an SGPR offset, so: keep the registers live across a few idle slots.
                         asm volatile("s_nop 7" ::"v"(packed), "v"(vo_c) : "memory");
+                        if constexpr (GN_OK) gpk[it] = packed;   // (M is a multiple of 32 whenever gn_out is set: every row of a live block is live)
                         if constexpr (FEAT == 3) {   // LayerNorm statistics of the values as STORED (bf16), for the consumer's fold
                             float g[8], s1 = 0.f, s2 = 0.f;
                             unpack8(__builtin_bit_cast(bf16x8_raw, packed), g);
@@ -1089,6 +1149,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                                 atomicAdd(rowacc + 2 * r + 1, s2);
                             }
                         }
+                    }
+                    if constexpr (GN_OK) {
+                        if (gn_on) gn_reduce_store(pi, gpk);
                     }
                 };
 
@@ -1502,6 +1565,13 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
                     "sdv_gemm_bf16: the LayerNorm fold / row statistics need the aligned epilogue");
     SDV_REQUIRE(a.alpha_cols >= 0 && a.alpha_cols % 8 == 0 && (a.alpha_cols == 0 || a.epi != 1),
                 "sdv_gemm_bf16: alpha_cols=%d must be a multiple of 8 (and is not available with GEGLU)", a.alpha_cols);
+    if (a.gn_out) {
+        const int nout = a.N;
+        SDV_REQUIRE(a.epi == 0 && !a.out_mode && !a.ln_side && !a.stats_out && !a.fp8 && a.M % 32 == 0 && (a.ldc & 7) == 0 && (nout & 7) == 0 &&
+                        (((uintptr_t)a.C | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0 && (!a.R || (a.ldr & 7) == 0) && ((a.sC | a.sR) & 7) == 0 &&
+                        a.gn_ld >= nout && (a.gn_ld & 3) == 0 && (((uintptr_t)a.gn_out) & 15) == 0,
+                    "sdv_gemm_bf16: gn_out needs the plain bf16 epilogue (epi 0, no fold / fp8 / out_mode), M %% 32 == 0 and aligned operands");
+    }
     hipStream_t s = (hipStream_t)stream;
     int tile = a.tile;
     const long long nb = a.batch > 0 ? a.batch : 1;

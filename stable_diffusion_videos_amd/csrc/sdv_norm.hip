@@ -324,6 +324,78 @@ __global__ __launch_bounds__(256) void layernorm320_kernel(const uint16_t* __res
 
 }  // namespace
 
+// ---- GroupNorm statistics from the producing igemm's epilogue (sdv_gemm_args.gn_out) ------------------------------------------
+// P [blocks][2][ld]: (sum, sumsq) per 32-row block and channel.  One workgroup per image: thread t sums its channels over the
+// image's blocks (fixed order), one thread per group folds the group's channels (fixed order) -> partials[img][0][group][2],
+// the layout sdv_groupnorm_apply reads with splits = 1.  Two sources = the channel concat of the up blocks (cat([x, skip])):
+// groups may straddle the seam, which is why the producers emit per-CHANNEL sums.
+namespace {
+struct GnSrc {
+    const float* P;
+    int C, ld, bpi, nrep;      // channels, row stride of P, 32-row blocks per image (and repetition), repetitions (mode 4: 4 phases)
+    long long rep_stride;      // blocks between two repetitions
+};
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnSrc a, GnSrc b, int groups, int splits, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [C][2]
+    const int C = a.C + b.C, cpg = C / groups;
+    const int img = blockIdx.x, split = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const GnSrc& s = c < a.C ? a : b;
+        const int cc = c < a.C ? c : c - a.C;
+        const int per = (s.bpi + splits - 1) / splits;
+        const int k0 = split * per, k1 = k0 + per < s.bpi ? k0 + per : s.bpi;
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < s.nrep; ++r) {
+            const float* base = s.P + ((r * s.rep_stride + (long long)img * s.bpi) * 2) * s.ld + cc;
+            int k = k0;
+            for (; k + 3 < k1; k += 4) {               // 8 independent loads in flight; the adds keep the block order
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = base[(long long)(2 * k + j) * s.ld];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s1 += t[2 * j];
+                    s2 += t[2 * j + 1];
+                }
+            }
+            for (; k < k1; ++k) {
+                s1 += base[(long long)(2 * k) * s.ld];
+                s2 += base[(long long)(2 * k + 1) * s.ld];
+            }
+        }
+        sm[2 * c] = s1;
+        sm[2 * c + 1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        float as = 0.f, aq = 0.f;
+        for (int c = 0; c < cpg; ++c) {
+            as += sm[2 * (threadIdx.x * cpg + c)];
+            aq += sm[2 * (threadIdx.x * cpg + c) + 1];
+        }
+        float* out = partials + (((long long)img * splits + split) * groups + threadIdx.x) * 2;
+        out[0] = as;
+        out[1] = aq;
+    }
+}
+}  // namespace
+
+extern "C" int sdv_groupnorm_finalize(const float* P1, int32_t C1, int32_t ld1, int32_t bpi1, int32_t nrep1, int64_t rep_stride1,
+                                      const float* P2, int32_t C2, int32_t ld2, int32_t bpi2, int32_t nrep2, int64_t rep_stride2,
+                                      int32_t nimg, int32_t groups, int32_t splits, float* partials, void* stream) {
+    SDV_REQUIRE(P1 && partials && C1 > 0 && nimg > 0, "sdv_groupnorm_finalize: bad args");
+    SDV_REQUIRE(C2 == 0 || P2, "sdv_groupnorm_finalize: C2 > 0 needs P2");
+    const int C = C1 + C2;
+    SDV_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "sdv_groupnorm_finalize: bad groups %d for C=%d", groups, C);
+    SDV_REQUIRE(bpi1 > 0 && nrep1 > 0 && (C2 == 0 || (bpi2 > 0 && nrep2 > 0)) && splits > 0 && splits <= 64, "sdv_groupnorm_finalize: bad block geometry");
+    SDV_REQUIRE((size_t)C * 8 <= 64 * 1024, "sdv_groupnorm_finalize: C=%d too large", C);
+    GnSrc a{P1, C1, ld1, bpi1, nrep1, rep_stride1};
+    GnSrc b{C2 ? P2 : P1, C2, C2 ? ld2 : ld1, C2 ? bpi2 : 1, C2 ? nrep2 : 1, C2 ? rep_stride2 : 0};
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg, splits), dim3(256), (size_t)C * 8, (hipStream_t)stream, a, b, groups, splits, partials);
+    SDV_CHECK_LAUNCH("sdv_groupnorm_finalize");
+    return SDV_OK;
+}
+
 extern "C" int sdv_groupnorm_stats(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg,
                                    int32_t HW, int32_t groups, int32_t splits, float* partials, void* stream) {
     SDV_REQUIRE(X && partials, "sdv_groupnorm_stats: null pointer");

@@ -137,16 +137,18 @@ class _Res:
         h = hip.groupnorm(x, self.g1, self.b1, nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True, x2=x2)
         if self.wt is not None:
             h = hip.conv3x3(h, self.w1, self.bias_table, nimg=nimg, H=H, W=W, circular=circular, step_ptr=step_ptr,
-                            bias_step_stride=self.cout)
+                            bias_step_stride=self.cout, gn=True)
         else:
-            h = hip.conv3x3(h, self.w1, self.c1_bias, nimg=nimg, H=H, W=W, circular=circular)
+            h = hip.conv3x3(h, self.w1, self.c1_bias, nimg=nimg, H=H, W=W, circular=circular, gn=True)
+        # (gn=True: the conv's epilogue also emits the per-channel statistics of what it stores, so norm2 - and, for conv2 below, the
+        #  next block's GroupNorm - runs no statistics pass of its own; hip.groupnorm picks them up from the tensor)
         h = hip.groupnorm(h, self.g2, self.b2, nimg=nimg, HW=HW, groups=self.groups, eps=self.eps, silu=True)
         if self.ws is not None:
             sc = hip.linear(x, self.ws, self.bs, x2=x2)
         else:
             assert x2 is None
             sc = x
-        return hip.conv3x3(h, self.w2, self.c2_bias, nimg=nimg, H=H, W=W, residual=sc, circular=circular, out=out)
+        return hip.conv3x3(h, self.w2, self.c2_bias, nimg=nimg, H=H, W=W, residual=sc, circular=circular, out=out, gn=True)
 
 
 class _Transformer:
@@ -281,12 +283,12 @@ class _Transformer:
         h = hip.linear(g, self.wff2, self.bff2, residual=h)
         _tap(self.name, "tf_ff", x=h_in, out=h, nimg=nimg, H=H, W=W)
         if not shared_prefix:
-            out = hip.linear(h, self.w_out, self.b_out, residual=x, out=out)
+            out = hip.linear(h, self.w_out, self.b_out, residual=x, out=out, gn_hw=HW)
         else:
             if out is None:
                 out = torch.empty((M, C), dtype=BF16, device=x.device)       # residual x is the shared (nb-sample) input
             hip.gemm(h, self.w_out, out, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.b_out, residual=x, ldr=C, batch=2,
-                     sX=Mb * C, sW=0, sC=Mb * C, sR=0)
+                     sX=Mb * C, sW=0, sC=Mb * C, sR=0, gn_hw=HW)
         _tap(self.name, "tf_out", x=h, x2=x, out=out, nimg=nimg, H=H, W=W, shared_prefix=shared_prefix)
         return out
 
@@ -505,15 +507,21 @@ class UNetEngine:
             return h
         out = torch.empty((nimg * HW, r.cout), dtype=BF16, device=self.device)
         vt = self._vt(nimg, t.C, HW) if t is not None else None
+        parts = []
         for lo in range(0, nimg, n):
             m = min(n, nimg - lo)
-            rows = slice(lo * HW, (lo + m) * HW)
-            sk = skip[rows] if skip is not None else None
+            # (the chunks carry their slice of the producers' GroupNorm statistics, and the chunks' own statistics are joined
+            #  again below: the chunked forward normalises with exactly the numbers of the whole-batch forward)
+            hs = hip.gn_slice(h, lo, m, HW)
+            sk = hip.gn_slice(skip, lo, m, HW) if skip is not None else None
+            o = out[lo * HW:(lo + m) * HW]
             if t is None:
-                r(h[rows], sk, m, hh, ww, step_ptr, circ, out=out[rows])
+                r(hs, sk, m, hh, ww, step_ptr, circ, out=o)
             else:
-                y = r(h[rows], sk, m, hh, ww, step_ptr, circ)
-                t(y, m, hh, ww, vt[:m], out=out[rows], ctx_of=(nimg, lo))
+                y = r(hs, sk, m, hh, ww, step_ptr, circ)
+                t(y, m, hh, ww, vt[:m], out=o, ctx_of=(nimg, lo))
+            parts.append(o)
+        hip.gn_join(parts, out)
         return out
 
     # -- one denoise forward -----------------------------------------------------------------
@@ -529,13 +537,16 @@ class UNetEngine:
         circ = self.tiled
         shared = bool(cfg_shared) and nimg % 2 == 0 and bool(self.down[0]["attn"])
         nb = nimg // 2 if shared else nimg
-        conv_in = hip.conv3x3_c4 if self.conv_in_c4 else hip.conv3x3_cin_small
-        h = conv_in(x[: nb * H * W], self.conv_in_w, self.conv_in_b, nimg=nb, H=H, W=W, circular=circ)
+        if self.conv_in_c4:
+            h = hip.conv3x3_c4(x[: nb * H * W], self.conv_in_w, self.conv_in_b, nimg=nb, H=H, W=W, circular=circ, gn=True)
+        else:
+            h = hip.conv3x3_cin_small(x[: nb * H * W], self.conv_in_w, self.conv_in_b, nimg=nb, H=H, W=W, circular=circ)
         _tap("conv_in", "conv", x=x[: nb * H * W], out=h, nimg=nb, H=H, W=W)
         if shared:
             h0 = torch.empty((nimg * H * W, h.shape[1]), dtype=BF16, device=self.device)   # skip tensor for the up path
             h0[: nb * H * W].copy_(h)
             h0[nb * H * W:].copy_(h)
+            hip.gn_repeat(h, h0, 2)         # (its GroupNorm statistics are conv_in's, twice)
             skips = [h0]
         else:
             skips = [h]
@@ -548,7 +559,7 @@ class UNetEngine:
             if blk["down"] is not None:
                 wd, bd = blk["down"]
                 h_in = h
-                h = hip.conv3x3(h, wd, bd, nimg=nimg, H=hh, W=ww, mode=2, circular=circ)
+                h = hip.conv3x3(h, wd, bd, nimg=nimg, H=hh, W=ww, mode=2, circular=circ, gn=True)
                 _tap(f"down_blocks.{bi}.downsamplers.0", "down", x=h_in, out=h, nimg=nimg, H=hh, W=ww)
                 hh, ww = (hh + 1) // 2, (ww + 1) // 2
                 skips.append(h)
@@ -562,7 +573,7 @@ class UNetEngine:
             if blk["up"] is not None:
                 wu, bu = blk["up"]
                 h_in = h
-                h = hip.upconv3x3_phase(h, wu, bu, nimg=nimg, H=hh, W=ww, circular=circ)      # Upsample2D: nearest 2x + conv
+                h = hip.upconv3x3_phase(h, wu, bu, nimg=nimg, H=hh, W=ww, circular=circ, gn=True)      # Upsample2D: nearest 2x + conv
                 _tap(f"up_blocks.{bi}.upsamplers.0", "up", x=h_in, out=h, nimg=nimg, H=hh, W=ww)
                 hh, ww = 2 * hh, 2 * ww
         h_in = h
@@ -638,7 +649,7 @@ class VAEDecoderEngine:
             hip.softmax_rows_(s, nb * HW, HW, HW)
             hip.gemm(s, vt, o, M=HW, N=C, K=HW, ldx=HW, ldw=HW, ldc=C, batch=nb, sX=HW * HW, sW=C * HW, sC=HW * C,
                      w_off=i0 * C * HW, out_off=i0 * HW * C)
-        return hip.linear(o, self.a_wo, self.a_bo, residual=x)
+        return hip.linear(o, self.a_wo, self.a_bo, residual=x, gn_hw=HW)
 
     def decode(self, latents: torch.Tensor, want_float: bool = False):
         """latents: fp32 NHWC [B, h, w, 4] (UNSCALED, as they leave the denoise loop).  Returns
@@ -648,8 +659,10 @@ class VAEDecoderEngine:
         z = torch.empty((B * h * w, lc), dtype=BF16, device=self.device)
         hip.latent_affine(latents.contiguous(), self.pq_w, self.pq_b, 1.0 / self.cfg.scaling_factor, z, B * h * w, lc)
         _tap("post_quant_conv", "post_quant", x=latents.reshape(B * h * w, lc), out=z, nimg=B, H=h, W=w)
-        conv_in = hip.conv3x3_c4 if self.conv_in_c4 else hip.conv3x3_cin_small
-        x = conv_in(z, self.conv_in_w, self.conv_in_b, nimg=B, H=h, W=w, circular=circ)
+        if self.conv_in_c4:
+            x = hip.conv3x3_c4(z, self.conv_in_w, self.conv_in_b, nimg=B, H=h, W=w, circular=circ, gn=True)
+        else:
+            x = hip.conv3x3_cin_small(z, self.conv_in_w, self.conv_in_b, nimg=B, H=h, W=w, circular=circ)
         _tap("decoder.conv_in", "conv", x=z, out=x, nimg=B, H=h, W=w)
         x = self.mid_res[0](x, None, B, h, w, None, circ)
         x = self._attention(x, B, h, w)
@@ -660,7 +673,7 @@ class VAEDecoderEngine:
             if blk["up"] is not None:
                 wu, bu = blk["up"]
                 x_in = x
-                x = hip.upconv3x3_phase(x, wu, bu, nimg=B, H=h, W=w, circular=circ)
+                x = hip.upconv3x3_phase(x, wu, bu, nimg=B, H=h, W=w, circular=circ, gn=True)
                 _tap(f"decoder.up_blocks.{bi}.upsamplers.0", "up", x=x_in, out=x, nimg=B, H=h, W=w)
                 h, w = 2 * h, 2 * w
         x_in = x

@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("alpha_cols", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
         ("fp8", C.c_int32), ("out_mode", C.c_int32), ("out_f32", C.c_void_p), ("out_u8", C.c_void_p),
-        ("k_order", C.c_int32), ("walk", C.c_int32),
+        ("k_order", C.c_int32), ("walk", C.c_int32), ("gn_out", C.c_void_p), ("gn_ld", C.c_int32),
     ]
 
 
@@ -56,6 +56,7 @@ _SIGNATURES = {
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdv_groupnorm_finalize": (C.c_int, ([C.c_void_p] + [C.c_int32] * 4 + [C.c_int64]) * 2 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
                             [C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -200,7 +201,63 @@ _GEMM_INTS = ("M", "N", "K", "ldx", "ldw", "ldc", "ldr", "C1", "ldx2", "epi", "m
               "out_mode", "k_order")
 
 
-def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32, out_u8, ints, alpha, ln_eps, want_stats):
+GN_EPILOGUE = os.environ.get("SDV_GN_EPILOGUE", "1") != "0"     # A/B knob: 0 = every GroupNorm runs its own statistics pass
+
+
+class GnStats:
+    """GroupNorm statistics that left the producing igemm's epilogue (sdv_gemm_args.gn_out): ``p`` fp32 [blocks, 2, C] of
+    (sum, sumsq) per 32-row block and channel of a tensor of ``nimg`` images with ``HW`` pixels each; ``nrep`` repetitions
+    ``rep_stride`` blocks apart (the four phases of a phase-form up-conv).  Travels as ``tensor._sdv_gn`` with the tensor the
+    producer returned; ``groupnorm`` uses it instead of a statistics pass when it matches what it is asked to normalise."""
+    __slots__ = ("p", "C", "nimg", "HW", "bpi", "nrep", "rep_stride")
+
+    def __init__(self, p, C, nimg, HW, bpi, nrep, rep_stride):
+        self.p, self.C, self.nimg, self.HW, self.bpi, self.nrep, self.rep_stride = p, C, nimg, HW, bpi, nrep, rep_stride
+
+
+def gn_repeat(t_src: torch.Tensor, t_dst: torch.Tensor, times: int):
+    """``t_dst`` holds ``times`` copies of ``t_src``'s images back to back (the CFG-shared skip tensor): its statistics are the
+    source's, repeated."""
+    g = getattr(t_src, "_sdv_gn", None)
+    if g is not None and g.nrep == 1:
+        t_dst._sdv_gn = GnStats(torch.cat([g.p] * times), g.C, g.nimg * times, g.HW, g.bpi, 1, 0)
+
+
+def gn_slice(t: torch.Tensor, first_img: int, n_img: int, HW: int) -> torch.Tensor:
+    """Rows of images [first_img, first_img + n_img) of ``t`` - with the matching slice of its epilogue statistics, so that a
+    forward that walks the batch in chunks of images normalises with exactly the numbers the whole-batch forward uses."""
+    out = t[first_img * HW:(first_img + n_img) * HW]
+    g = getattr(t, "_sdv_gn", None)
+    if g is not None and g.HW == HW:
+        if g.nrep == 1:
+            p = g.p[first_img * g.bpi:(first_img + n_img) * g.bpi]
+            out._sdv_gn = GnStats(p, g.C, n_img, HW, g.bpi, 1, 0)
+        else:
+            p = g.p.view(g.nrep, g.rep_stride, 2, g.C)[:, first_img * g.bpi:(first_img + n_img) * g.bpi].contiguous()
+            out._sdv_gn = GnStats(p.view(-1, 2, g.C), g.C, n_img, HW, g.bpi, g.nrep, n_img * g.bpi)
+    return out
+
+
+def gn_join(parts, whole: torch.Tensor):
+    """The statistics of ``whole`` from those of its consecutive image chunks ``parts`` (all produced with nrep == 1)."""
+    gs = [getattr(t, "_sdv_gn", None) for t in parts]
+    if gs and all(g is not None and g.nrep == 1 for g in gs):
+        whole._sdv_gn = GnStats(torch.cat([g.p for g in gs]), gs[0].C, sum(g.nimg for g in gs), gs[0].HW, gs[0].bpi, 1, 0)
+
+
+def gn_epilogue_ok(*, M, N, epi, mode, ldc, ldr, out, bias, residual, fp8, ln, want_stats, out_mode, HW_out, batch, sC, sR) -> bool:
+    """Can this igemm launch emit the GroupNorm statistics of its output (sdv_hip.h gn_out)?  ``HW_out``: pixels per image of the
+    OUTPUT tensor.  Mirrors the checks of sdv_gemm_bf16."""
+    if not GN_EPILOGUE or epi != 0 or out_mode or fp8 or ln is not None or want_stats or out is None:
+        return False
+    rows_per_image = HW_out // 4 if mode == 4 else HW_out           # rows of ONE launch phase that belong to one image
+    if M % 32 or rows_per_image % 32 or N % 8 or ldc % 8 or (residual is not None and ldr % 8) or (sC | sR) % 8:
+        return False
+    ptrs = out.data_ptr() | (bias.data_ptr() if bias is not None else 0) | (residual.data_ptr() if residual is not None else 0)
+    return ptrs % 16 == 0
+
+
+def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32, out_u8, gn_out, ints, alpha, ln_eps, want_stats):
     """sdv::k_igemm - the launch of ``sdv_gemm_bf16`` (+ ``sdv_rowstats_finalize`` when the row statistics are wanted)."""
     g = dict(zip(_GEMM_INTS, ints))
     M, N, K, batch, mode, epi = g["M"], g["N"], g["K"], g["batch"], g["mode"], g["epi"]
@@ -234,6 +291,8 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
         a.tile = FORCE_TILE
     if ln_stats is not None:
         a.ln_stats, a.ln_s, a.ln_side = _ptr(ln_stats, F32, "ln_stats"), _ptr(ln_s, F32, "ln_s"), g["ln_side"]
+    if gn_out is not None:
+        a.gn_out, a.gn_ld = _ptr(gn_out, F32, "gn_out"), gn_out.shape[-1]
     partials = None
     if want_stats:
         a.stats_out = 16          # (non-null while planning: the tile choice depends on it)
@@ -259,14 +318,14 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
     return torch.empty(0, dtype=F32, device=x.device)
 
 
-def _igemm_fake(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32, out_u8, ints, alpha, ln_eps, want_stats):
+def _igemm_fake(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32, out_u8, gn_out, ints, alpha, ln_eps, want_stats):
     g = dict(zip(_GEMM_INTS, ints))
     return x.new_empty((max(g["batch"], 1) * g["M"], 2) if want_stats else (0,), dtype=F32)
 
 
 _k_igemm = _defop("k_igemm(Tensor x, Tensor w, Tensor(a!)? out, Tensor? bias, Tensor? residual, Tensor? x2, Tensor? ln_stats, "
-                  "Tensor? ln_s, Tensor? step_ptr, Tensor(b!)? out_f32, Tensor(c!)? out_u8, int[] ints, float alpha, float ln_eps, "
-                  "bool want_stats) -> Tensor", _igemm_impl, _igemm_fake)
+                  "Tensor? ln_s, Tensor? step_ptr, Tensor(b!)? out_f32, Tensor(c!)? out_u8, Tensor(d!)? gn_out, int[] ints, float alpha, "
+                  "float ln_eps, bool want_stats) -> Tensor", _igemm_impl, _igemm_fake)
 
 
 def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, ldx: int, ldw: int,
@@ -277,22 +336,38 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
          x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None, ln_side: int = 1,
          want_stats: bool = False, ln_eps: float = 1e-5, out_mode: int = 0, out_f32: Optional[torch.Tensor] = None,
-         out_u8: Optional[torch.Tensor] = None, k_order: int = -1):
+         out_u8: Optional[torch.Tensor] = None, k_order: int = -1, gn_hw: int = 0):
     """``sdv_gemm_bf16`` through ``torch.ops.sdv.k_igemm`` (element offsets x_off / w_off / out_off select sub-matrices).
     ``out_mode`` 1 / 2: fp32 output / image epilogue into ``out_f32`` / ``out_u8`` (``out`` may be None), see sdv_hip.h.
     ``ln=(stats, s)``: LayerNorm folded into this GEMM (sdv_hip.h): ``stats`` fp32 [rows, 2] = (mean, rstd) from
     ``want_stats`` of the producer, ``s`` fp32 row sums of the gamma-scaled weights.  ``want_stats=True`` returns the
-    (mean, rstd) [batch*M, 2] of this GEMM's OUTPUT rows over its N columns (for the next LayerNorm)."""
+    (mean, rstd) [batch*M, 2] of this GEMM's OUTPUT rows over its N columns (for the next LayerNorm).
+    ``gn_hw`` > 0: the output is an NHWC image tensor with ``gn_hw`` pixels per image whose next consumer is a GroupNorm - where the
+    launch qualifies (``gn_epilogue_ok``) the epilogue also emits the per-channel statistics and ``out._sdv_gn`` carries them."""
     ints = [M, N, K, ldx, ldw, ldc, ldr, C1, ldx2, epi, mode, Hin, Win, Hout, Wout, int(circular), batch, sX, sW, sC, sR, bias_mode,
             bias_step_stride, tile, x_off, w_off, out_off, alpha_cols, ln_side, out_mode, k_order]
+    gn_out = None
+    nb = max(batch, 1)
+    if gn_hw and out_off == 0 and gn_epilogue_ok(M=M, N=N, epi=epi, mode=mode, ldc=ldc, ldr=ldr, out=out, bias=bias, residual=residual,
+                                                 fp8=x.dtype == FP8, ln=ln, want_stats=want_stats, out_mode=out_mode, HW_out=gn_hw,
+                                                 batch=batch, sC=sC, sR=sR):
+        nrep = 4 if mode == 4 else 1
+        rows = nb * M if mode != 4 else M                       # rows of one repetition
+        gn_out = torch.empty((nrep * rows // 32, 2, N), dtype=F32, device=x.device)
     st = _k_igemm(x, w, out, bias, residual, x2, ln[0] if ln is not None else None, ln[1] if ln is not None else None, step_ptr,
-                  out_f32, out_u8, ints, float(alpha), float(ln_eps), bool(want_stats))
+                  out_f32, out_u8, gn_out, ints, float(alpha), float(ln_eps), bool(want_stats))
+    if gn_out is not None:
+        rows_per_image = gn_hw // 4 if mode == 4 else gn_hw
+        nimg = (M if mode == 4 else nb * M) // rows_per_image
+        out._sdv_gn = GnStats(gn_out, N, nimg, gn_hw, rows_per_image // 32, 4 if mode == 4 else 1, (M // 32) if mode == 4 else 0)
+    elif out is not None and hasattr(out, "_sdv_gn"):
+        del out._sdv_gn
     return st if want_stats else None
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, residual=None, out=None,
            epi: int = 0, x2: Optional[torch.Tensor] = None, alpha: float = 1.0, tile: int = 0, alpha_cols: int = 0, ln=None,
-           want_stats: bool = False, ln_eps: float = 1e-5):
+           want_stats: bool = False, ln_eps: float = 1e-5, gn_hw: int = 0):
     """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias) (+ residual); x2 = optional second K-source (concat).
     ``ln`` / ``want_stats``: see ``gemm`` (with want_stats the return value is ``(y, stats)``)."""
     M, K1 = x.shape
@@ -306,14 +381,14 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     st = gemm(x, w, out, M=M, N=N, K=K, ldx=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias,
               residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2, C1=K1 if x2 is not None else 0,
               ldx2=x2.stride(0) if x2 is not None else 0, alpha=alpha, epi=epi, tile=tile, alpha_cols=alpha_cols, ln=ln,
-              want_stats=want_stats, ln_eps=ln_eps)
+              want_stats=want_stats, ln_eps=ln_eps, gn_hw=gn_hw)
     return (out, st) if want_stats else out
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, nimg: int, H: int, W: int,
             mode: int = 1, x2: Optional[torch.Tensor] = None, residual=None, circular: bool = False,
             step_ptr=None, bias_step_stride: int = 0, out=None, tile: int = 0, epi: int = 0,
-            alpha: float = 1.0, out_mode: int = 0, out_f32=None, out_u8=None) -> torch.Tensor:
+            alpha: float = 1.0, out_mode: int = 0, out_f32=None, out_u8=None, gn: bool = False) -> torch.Tensor:
     """NHWC conv3x3 pad 1.  x: [nimg*H*W, C1] (+ x2 [.., C2]); w: [Cout, 9*(C1+C2)] (OHWI).
     mode 1: stride 1; 2: stride 2; 3: nearest-2x upsample then conv.  x / out / residual may be column
     slices of wider row-major buffers (row stride = .stride(0)): dense-block concat without copies.
@@ -325,7 +400,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
     if w.shape[1] != 9 * (C1 + C2):
         raise SdvHipError(f"conv3x3: weight K {w.shape[1]} != 9*{C1 + C2}")
     if mode == 4:
-        return upconv3x3_phase(x, w, bias, nimg=nimg, H=H, W=W, circular=circular, out=out, tile=tile)
+        return upconv3x3_phase(x, w, bias, nimg=nimg, H=H, W=W, circular=circular, out=out, tile=tile, gn=gn)
     if mode == 1:
         Ho, Wo = H, W
     elif mode == 2:
@@ -345,12 +420,12 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n
          residual=residual, ldr=residual.stride(0) if residual is not None else 0, x2=x2,
          C1=C1 if x2 is not None else 0, ldx2=x2.stride(0) if x2 is not None else 0, mode=mode, Hin=H, Win=W,
          Hout=Ho, Wout=Wo, circular=circular, step_ptr=step_ptr, bias_step_stride=bias_step_stride, tile=tile,
-         epi=epi, alpha=alpha, out_mode=out_mode, out_f32=out_f32, out_u8=out_u8)
+         epi=epi, alpha=alpha, out_mode=out_mode, out_f32=out_f32, out_u8=out_u8, gn_hw=Ho * Wo if gn else 0)
     return out
 
 
 def upconv3x3_phase(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor], *, nimg: int, H: int, W: int,
-                    circular: bool = False, out=None, tile: int = 0) -> torch.Tensor:
+                    circular: bool = False, out=None, tile: int = 0, gn: bool = False) -> torch.Tensor:
     """Upsample2D (nearest 2x, then conv3x3 pad 1) in phase form: x [nimg*H*W, Cin] -> [nimg*2H*2W, Cout].
     ``w4``: [4*Cout, 4*Cin] from ``weights.upconv_phase_w`` (phase-major; 2x2 taps with the coincident 3x3 taps summed)."""
     Cin = x.shape[1]
@@ -360,7 +435,7 @@ def upconv3x3_phase(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tens
     if out is None:
         out = torch.empty((nimg * 4 * H * W, Cout), dtype=BF16, device=x.device)
     gemm(x, w4, out, M=nimg * H * W, N=Cout, K=Cin, ldx=x.stride(0), ldw=w4.stride(0), ldc=out.stride(0), bias=bias, mode=4,
-         Hin=H, Win=W, Hout=H, Wout=W, circular=circular, tile=tile)
+         Hin=H, Win=W, Hout=H, Wout=W, circular=circular, tile=tile, gn_hw=4 * H * W if gn else 0)
     return out
 
 
@@ -414,22 +489,36 @@ def gn_splits(HW: int) -> int:
     return max(1, min(64, HW // pix))
 
 
-def _groupnorm_impl(x, gamma, beta, x2, out, ints, eps, fp8_scale):
-    nimg, HW, groups, silu = ints
+def _groupnorm_impl(x, gamma, beta, x2, out, p1, p2, ints, eps, fp8_scale):
+    nimg, HW, groups, silu, bpi1, nrep1, rs1, bpi2, nrep2, rs2 = ints
     lib = load()
     C1 = x.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
-    splits = gn_splits(HW)
-    partials = torch.empty((nimg, splits, groups, 2), dtype=F32, device=x.device)
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise SdvHipError("groupnorm: inputs must be contiguous")
     fp8 = fp8_scale > 0.0
     nbytes = 2.0 * nimg * HW * (C1 + C2)
-    xp, x2p, pp, op = _ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), _ptr(partials), _ptr(out, FP8 if fp8 else BF16, "Y")
+    if p1 is not None:
+        # statistics from the producers' epilogues (sdv_gemm_args.gn_out): only their per-block partials are read
+        splits = max(1, min(64, (bpi1 * nrep1) // 16))          # 16 of an image's 32-row blocks per finalize workgroup
+        partials = torch.empty((nimg, splits, groups, 2), dtype=F32, device=x.device)
+        pp = _ptr(partials)
+        q1, q2 = _ptr(p1, F32, "gn partials"), _ptr(p2, F32, "gn partials 2")
+        ld1, ld2 = p1.shape[-1], (p2.shape[-1] if p2 is not None else 0)
+        fbytes = 4.0 * (p1.numel() + (p2.numel() if p2 is not None else 0))
+        _launch("gn_finalize", dict(bytes=fbytes),
+                lambda: _check(lib.sdv_groupnorm_finalize(q1, C1, ld1, bpi1, nrep1, rs1, q2, C2, ld2, bpi2, nrep2, rs2, nimg, groups, splits,
+                                                          pp, _stream()), "sdv_groupnorm_finalize"))
+    else:
+        splits = gn_splits(HW)
+        partials = torch.empty((nimg, splits, groups, 2), dtype=F32, device=x.device)
+        pp = _ptr(partials)
+    xp, x2p, op = _ptr(x, BF16, "X"), _ptr(x2, BF16, "X2"), _ptr(out, FP8 if fp8 else BF16, "Y")
     gp, bp = _ptr(gamma, F32, "gamma"), _ptr(beta, F32, "beta")
-    _launch("gn_stats", dict(bytes=nbytes),
-            lambda: _check(lib.sdv_groupnorm_stats(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, _stream()),
-                           "sdv_groupnorm_stats"))
+    if p1 is None:
+        _launch("gn_stats", dict(bytes=nbytes),
+                lambda: _check(lib.sdv_groupnorm_stats(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, _stream()),
+                               "sdv_groupnorm_stats"))
     if fp8:
         _launch("gn_apply", dict(bytes=1.5 * nbytes),
                 lambda: _check(lib.sdv_groupnorm_apply_fp8(xp, x2p, C1, C2, nimg, HW, groups, splits, pp, gp, bp, eps, int(silu),
@@ -440,20 +529,35 @@ def _groupnorm_impl(x, gamma, beta, x2, out, ints, eps, fp8_scale):
                                                    op, _stream()), "sdv_groupnorm_apply"))
 
 
-_k_groupnorm = _defop("k_groupnorm(Tensor x, Tensor gamma, Tensor beta, Tensor? x2, Tensor(a!) out, int[] ints, float eps, "
-                      "float fp8_scale) -> ()", _groupnorm_impl)
+_k_groupnorm = _defop("k_groupnorm(Tensor x, Tensor gamma, Tensor beta, Tensor? x2, Tensor(a!) out, Tensor? gn1, Tensor? gn2, int[] ints, "
+                      "float eps, float fp8_scale) -> ()", _groupnorm_impl)
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg: int, HW: int, groups: int,
               eps: float, silu: bool, x2: Optional[torch.Tensor] = None, out=None, fp8_scale: Optional[float] = None) -> torch.Tensor:
     """GroupNorm(+SiLU) over NHWC [nimg*HW, C1] (++ [.., C2] concatenated on channels) -> bf16 [.., C1+C2]
-    (``torch.ops.sdv.k_groupnorm``: statistics pass + apply pass).
+    (``torch.ops.sdv.k_groupnorm``: statistics pass + apply pass).  When ``x`` (and ``x2``) carry the statistics their producer's
+    epilogue emitted (``tensor._sdv_gn``, see ``gemm(gn_hw=)``) and those describe exactly this tensor, the statistics pass is
+    replaced by ``sdv_groupnorm_finalize`` over the per-block partials.
     ``fp8_scale`` s: the result is written as OCP e4m3 bytes q = sat(y / s) instead (y ~ q * s), the fp8 conv's operand."""
     C1 = x.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     if out is None:
         out = torch.empty((nimg * HW, C1 + C2), dtype=BF16 if fp8_scale is None else FP8, device=x.device)
-    _k_groupnorm(x, gamma, beta, x2, out, [nimg, HW, groups, int(silu)], float(eps), float(fp8_scale) if fp8_scale is not None else 0.0)
+    g1 = getattr(x, "_sdv_gn", None) if GN_EPILOGUE else None
+    g2 = getattr(x2, "_sdv_gn", None) if (x2 is not None and GN_EPILOGUE) else None
+
+    def fits(g, t):
+        return g is not None and g.nimg == nimg and g.HW == HW and g.C == t.shape[1] and t.shape[0] == nimg * HW
+
+    geo = [0, 1, 0, 0, 1, 0]
+    p1 = p2 = None
+    if fits(g1, x) and (x2 is None or fits(g2, x2)):
+        p1, geo[0:3] = g1.p, [g1.bpi, g1.nrep, g1.rep_stride]
+        if x2 is not None:
+            p2, geo[3:6] = g2.p, [g2.bpi, g2.nrep, g2.rep_stride]
+    _k_groupnorm(x, gamma, beta, x2, out, p1, p2, [nimg, HW, groups, int(silu)] + geo, float(eps),
+                 float(fp8_scale) if fp8_scale is not None else 0.0)
     return out
 
 
@@ -510,14 +614,14 @@ def _im2col3x3_c4_impl(x, cols, nimg, H, W, circular):
 _k_im2col3x3_c4 = _defop("k_im2col3x3_c4(Tensor x, Tensor(a!) cols, int nimg, int H, int W, bool circular) -> ()", _im2col3x3_c4_impl)
 
 
-def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False, out=None):
+def conv3x3_c4(x, w_pad, bias, *, nimg, H, W, circular=False, out=None, gn: bool = False):
     """3x3 pad-1 conv of a 4-channel NHWC tensor on the matrix cores: im2col to 64-wide rows + K = 64 GEMM.
     ``w_pad``: [Cout, 64] = OHWI weights [Cout, 36] zero-padded (see ``weights.conv_w_c4``)."""
     if x.shape[1] != 4:
         raise SdvHipError(f"conv3x3_c4: expected 4 input channels, got {x.shape[1]}")
     cols = torch.empty((nimg * H * W, 64), dtype=BF16, device=x.device)
     _k_im2col3x3_c4(x, cols, nimg, H, W, bool(circular))
-    return linear(cols, w_pad, bias, out=out)
+    return linear(cols, w_pad, bias, out=out, gn_hw=H * W if gn else 0)
 
 
 def embed_tokens(ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:

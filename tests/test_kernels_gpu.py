@@ -913,3 +913,117 @@ def test_groupnorm_fp8_output(hip, dev):
     d = (q.float() * s - y).abs()
     ulp = torch.exp2(torch.floor(torch.log2((y.abs() / s).clamp_min(2.0 ** -6))) - 3) * s      # e4m3: 3 mantissa bits
     assert float((d / ulp).max()) <= 0.75      # half an ulp + the fp32 differences of the two evaluations of y
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm statistics out of the producing igemm's epilogue (sdv_gemm_args.gn_out + sdv_groupnorm_finalize)
+# ------------------------------------------------------------------------------------------------
+def _gn_ref_blocks(out, nblocks):
+    o = out.float().view(nblocks, 32, -1)
+    return o.sum(1), (o * o).sum(1)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("kind", ["dense", "dense_res", "conv", "conv_res", "conv_s2", "dense_batch2"])
+def test_igemm_epilogue_emits_groupnorm_statistics(hip, dev, tile, kind):
+    """Every (32-row block, channel) entry of gn_out is the (sum, sumsq) of the bf16 values the launch STORED - compared with a
+    float64 reduction of the output tensor itself (so the check is independent of the GEMM's own accuracy): the fp32 in-kernel
+    sums of 32 values differ by <= 32 * 2^-24 relative of sum|x| / sum x^2.  Ragged N (320 on 256-column tiles), several tiles
+    per launch, all tiles that carry the row-major store sequence."""
+    nimg, H, W, Cin, Cout = 3, 16, 16, 128, 320
+    x = rnd((nimg * H * W, Cin), dev, 201).to(BF16)
+    bias = rnd((Cout,), dev, 203)
+    if kind.startswith("dense"):
+        w = rnd((Cout, Cin), dev, 202, Cin ** -0.5).to(BF16)
+        if kind == "dense_batch2":          # the CFG-shared proj_out: two batches read one residual (batch stride 0)
+            M = nimg * H * W
+            x2b = torch.cat([x, rnd((M, Cin), dev, 205).to(BF16)])
+            res = rnd((M, Cout), dev, 204).to(BF16)
+            out = torch.empty((2 * M, Cout), dtype=BF16, device=dev)
+            hip.gemm(x2b, w, out, M=M, N=Cout, K=Cin, ldx=Cin, ldw=Cin, ldc=Cout, bias=bias, residual=res, ldr=Cout, batch=2,
+                     sX=M * Cin, sW=0, sC=M * Cout, sR=0, gn_hw=H * W, tile=tile)
+            nb_img = 2 * nimg
+        else:
+            res = rnd((nimg * H * W, Cout), dev, 204).to(BF16) if kind == "dense_res" else None
+            out = hip.linear(x, w, bias, residual=res, gn_hw=H * W, tile=tile)
+            nb_img = nimg
+        Ho = H
+    else:
+        w = rnd((Cout, 9 * Cin), dev, 202, (9 * Cin) ** -0.5).to(BF16)
+        mode = 2 if kind == "conv_s2" else 1
+        Ho = H // 2 if mode == 2 else H
+        res = rnd((nimg * Ho * Ho, Cout), dev, 204).to(BF16) if kind == "conv_res" else None
+        out = hip.conv3x3(x, w, bias, nimg=nimg, H=H, W=W, mode=mode, residual=res, gn=True, tile=tile)
+        nb_img = nimg
+    torch.cuda.synchronize()
+    g = getattr(out, "_sdv_gn", None)
+    assert g is not None and (g.nimg, g.HW, g.C, g.nrep) == (nb_img, Ho * Ho, Cout, 1)
+    nblocks = out.shape[0] // 32
+    assert tuple(g.p.shape) == (nblocks, 2, Cout) and g.bpi == Ho * Ho // 32
+    s_ref, q_ref = _gn_ref_blocks(out.double(), nblocks)
+    a_ref, _ = _gn_ref_blocks(out.double().abs(), nblocks)
+    assert float(((g.p[:, 0].double() - s_ref).abs() / (a_ref + 1e-30)).max()) < 4e-6
+    assert float(((g.p[:, 1].double() - q_ref).abs() / (q_ref + 1e-30)).max()) < 4e-6
+
+
+def test_upconv_phase_form_emits_groupnorm_statistics(hip, dev):
+    from stable_diffusion_videos_amd.weights import upconv_phase_w
+    nimg, H, W, C = 2, 16, 16, 320
+    x = rnd((nimg * H * W, C), dev, 211).to(BF16)
+    w = rnd((C, C, 3, 3), dev, 212, (9 * C) ** -0.5)
+    out = hip.upconv3x3_phase(x, upconv_phase_w(w.cpu(), dev), rnd((C,), dev, 213), nimg=nimg, H=H, W=W, gn=True)
+    torch.cuda.synchronize()
+    g = out._sdv_gn
+    assert (g.nimg, g.HW, g.C, g.nrep, g.bpi, g.rep_stride) == (nimg, 4 * H * W, C, 4, H * W // 32, nimg * H * W // 32)
+    # per image and channel: the four phases' blocks of the image add up to the image's sums
+    p = g.p.double().view(4, nimg, H * W // 32, 2, C).sum((0, 2))
+    o = out.double().view(nimg, 4 * H * W, C)
+    assert float(((p[:, 0] - o.sum(1)).abs() / o.abs().sum(1)).max()) < 4e-6
+    assert float(((p[:, 1] - (o * o).sum(1)).abs() / (o * o).sum(1)).max()) < 4e-6
+
+
+@pytest.mark.parametrize("concat", [False, True])
+def test_groupnorm_on_epilogue_statistics_matches_the_statistics_pass(hip, dev, concat):
+    """GroupNorm fed by the producers' statistics (finalize + apply) against the same GroupNorm with its own statistics pass over
+    the same tensors.  960 channels / 32 groups = 30 per group: with a 640 + 320 concat the group [630, 660) straddles the seam,
+    which is why the producers emit per-channel sums.  The two agree to fp32 summation order: <= 1 bf16 ulp on a few elements
+    (or 1e-4 absolute where the normalised value cancels to ~0 and an ulp of the result means nothing)."""
+    nimg, H, C1, C2 = 4, 32, 640, 320
+    HW = H * H
+    xa = rnd((nimg * HW, 128), dev, 221).to(BF16)
+    a = hip.linear(xa, rnd((C1, 128), dev, 222, 128 ** -0.5).to(BF16), rnd((C1,), dev, 223), gn_hw=HW)
+    b = hip.upconv3x3_phase(rnd((nimg * HW // 4, 128), dev, 224).to(BF16), __import__("stable_diffusion_videos_amd.weights", fromlist=["x"]).upconv_phase_w(
+        rnd((C2, 128, 3, 3), dev, 225, (9 * 128) ** -0.5).cpu(), dev), rnd((C2,), dev, 226), nimg=nimg, H=H // 2, W=H // 2, gn=True) if concat else None
+    C = C1 + (C2 if concat else 0)
+    gamma, beta = 1.0 + 0.1 * rnd((C,), dev, 227), 0.1 * rnd((C,), dev, 228)
+    seen = []
+    hip.LAUNCH_HOOK = lambda kind, info, fn: (seen.append(kind), fn())
+    try:
+        fast = hip.groupnorm(a, gamma, beta, nimg=nimg, HW=HW, groups=32, eps=1e-5, silu=True, x2=b)
+    finally:
+        hip.LAUNCH_HOOK = None
+    assert seen == ["gn_finalize", "gn_apply"]
+    a2, b2 = a.clone(), (b.clone() if concat else None)          # clones carry no statistics -> the statistics pass runs
+    seen.clear()
+    hip.LAUNCH_HOOK = lambda kind, info, fn: (seen.append(kind), fn())
+    try:
+        slow = hip.groupnorm(a2, gamma, beta, nimg=nimg, HW=HW, groups=32, eps=1e-5, silu=True, x2=b2)
+    finally:
+        hip.LAUNCH_HOOK = None
+    assert seen == ["gn_stats", "gn_apply"]
+    torch.cuda.synchronize()
+    d = (fast.float() - slow.float()).abs()
+    ulp = torch.exp2(torch.floor(torch.log2(slow.float().abs().clamp_min(1e-30))) - 7)
+    assert bool(((d <= ulp) | (d <= 1e-4)).all()) and float((d > 0).float().mean()) < 0.02
+    ref_in = torch.cat([a.float(), b.float()], 1) if concat else a.float()
+    ref = F.silu(F.group_norm(ref_in.view(nimg, HW, C).transpose(1, 2), 32, gamma, beta, 1e-5)).transpose(1, 2).reshape(nimg * HW, C)
+    assert rel_l2(fast.float(), ref) < 4e-3
+    # a tensor whose statistics describe another shape is not trusted: half the images -> the statistics pass
+    seen.clear()
+    hip.LAUNCH_HOOK = lambda kind, info, fn: (seen.append(kind), fn())
+    try:
+        if not concat:
+            hip.groupnorm(a, gamma, beta, nimg=nimg // 2, HW=2 * HW, groups=32, eps=1e-5, silu=True)
+    finally:
+        hip.LAUNCH_HOOK = None
+    assert concat or seen == ["gn_stats", "gn_apply"]
