@@ -105,8 +105,11 @@ typedef struct sdv_gemm_args {
      * (E8M0 127) - 64 K values per instruction at twice the bf16 / plain fp8 rate, two 64-wide K images per barrier interval;
      * tap-major K order only.  Same products as fp8 == 1: the results differ by the fp32 summation order at most. */
     int32_t fp8;
-    /* out_mode != 0: the output leaves in another type than bf16 (C may then be NULL), N <= 32, 4-wave tiles only (auto: 256x32):
-     *   1  out_f32 [M][ldc] fp32                                    (UNet conv_out 320 -> 4: the noise prediction stays fp32)
+    /* out_mode != 0: the output leaves in another type than bf16 (C may then be NULL), 4-wave tiles only (auto: 256x32 for
+     * N <= 32, 256x128 for wide outputs); the image forms 2 / 3 need N <= 32 and no batch:
+     *   1  out_f32 [batch][M][ldc] fp32, batch stride sC (in floats), any N   (UNet conv_out 320 -> 4: the noise prediction stays
+     *      fp32; the VAE mid-block attention's Q K^T: the scores reach sdv_softmax_rows_f32 unrounded - AttentionBlock of
+     *      AutoencoderKL.decode, stable_diffusion_pipeline.py:433)
      *   2  image epilogue of the VAE's conv_out 128 -> 3 (stable_diffusion_pipeline.py:432-438 + numpy_to_pil :450):
      *      v = clamp(v / 2 + 0.5, 0, 1) -> out_f32 [M][ldc] (optional) and out_u8 [M][ldc] = round-half-even(255 v) (optional)
      *   3  as 2 with v = clamp(v, 0, 1)            (RRDBNet conv_last of the Real-ESRGAN upsampler, upsampling.py:25-28)
@@ -173,8 +176,12 @@ int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt,
                        int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, int32_t causal,
                        int32_t q_prescaled, void* stream);
 
-/* row softmax in place over bf16 rows (VAE mid-block attention, 1 head x 512 channels) */
+/* row softmax in place over bf16 rows (1 head x 512 channels; kept for callers that hold bf16 scores) */
 int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, int32_t ld, void* stream);
+/* row softmax of fp32 scores S [rows][lds] into bf16 probabilities P [rows][ldp] (P != S): torch.softmax(scores.float(), -1) of the
+ * VAE mid-block attention (vae.decode, stable_diffusion_pipeline.py:433) - with sdv_gemm_args.out_mode 1 the scores are never
+ * rounded to bf16, the probabilities are rounded once (as inside the flash kernel).  cols % 8 == 0, ldp % 8 == 0, lds % 4 == 0. */
+int sdv_softmax_rows_f32(const float* S, sdv_bf16* P, int64_t rows, int32_t cols, int32_t lds, int32_t ldp, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (32 groups in SD) over NHWC activations, optionally over the channel-concat of two

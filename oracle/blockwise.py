@@ -53,7 +53,7 @@ BOUND_ROUNDINGS = {
     "tf_out": 1,          # proj_out + residual
     "out": 1,             # conv_norm_out+SiLU out (conv_out itself leaves in fp32)
     "post_quant": 1,
-    "vae_attention": 7,   # GN out, [Q|K], V^T, scores (bf16 in HBM - the weak one), P, P.V out, to_out+res
+    "vae_attention": 6,   # GN out, [Q|K], V^T, P, P.V out, to_out+res (the scores stay fp32 since round 4: sdv_gemm out_mode 1)
     "vae_out": 1,
 }
 

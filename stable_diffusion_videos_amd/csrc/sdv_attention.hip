@@ -545,6 +545,47 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(uint16_t* __restrict_
     }
 }
 
+// ---- row softmax of fp32 scores into bf16 probabilities (VAE mid-block attention: the scores leave the Q K^T GEMM unrounded) ----
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __restrict__ S, uint16_t* __restrict__ P, int cols, int lds, int ldp) {
+    __shared__ float red[8];
+    const float* row = S + (long long)blockIdx.x * lds;
+    uint16_t* prow = P + (long long)blockIdx.x * ldp;
+    const int tid = threadIdx.x;
+    auto load8 = [&](int c, float* f) {
+        const float4 a = *(const float4*)(row + c), b = *(const float4*)(row + c + 4);
+        f[0] = a.x, f[1] = a.y, f[2] = a.z, f[3] = a.w, f[4] = b.x, f[5] = b.y, f[6] = b.z, f[7] = b.w;
+    };
+    float mx = -INFINITY;
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        float f[8];
+        load8(c, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[e]);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        float f[8];
+        load8(c, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __expf(f[e] - mx);
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        float f[8];
+        load8(c, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = __expf(f[e] - mx) * inv;
+        *(bf16x8_raw*)(prow + c) = pack8(f);
+    }
+}
+
 }  // namespace
 
 extern "C" int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O, int32_t B,
@@ -571,5 +612,14 @@ extern "C" int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, in
     SDV_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "sdv_softmax_rows_bf16: cols/ld must be multiples of 8");
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, cols, ld);
     SDV_CHECK_LAUNCH("sdv_softmax_rows_bf16");
+    return SDV_OK;
+}
+
+extern "C" int sdv_softmax_rows_f32(const float* S, sdv_bf16* P, int64_t rows, int32_t cols, int32_t lds, int32_t ldp, void* stream) {
+    SDV_REQUIRE(S && P && rows > 0 && cols > 0, "sdv_softmax_rows_f32: bad args");
+    SDV_REQUIRE(cols % 8 == 0 && lds % 4 == 0 && ldp % 8 == 0 && lds >= cols && ldp >= cols, "sdv_softmax_rows_f32: cols / ldp must be multiples of 8, lds of 4");
+    SDV_REQUIRE(((((uintptr_t)S) | ((uintptr_t)P)) & 15) == 0, "sdv_softmax_rows_f32: unaligned pointers");
+    hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, P, cols, lds, ldp);
+    SDV_CHECK_LAUNCH("sdv_softmax_rows_f32");
     return SDV_OK;
 }

@@ -38,6 +38,13 @@
 #define SDV_GELU_FAST 1
 #endif
 
+// +residual epilogue of the tiles with two staging slabs per wave: 1 = 64-column fp32 passes through ONE 8.5 KB slab (32 rows x
+// (256 + 16) bytes) - every residual load and every store then covers 8 rows x 128 B, whole cache lines; 0 = 32-column fp32 passes
+// through two 4.5 KB slabs (16 rows x 64 B per instruction) - kept for A/B builds (tools/ubench/build_variant.py res32 -DSDV_RES_PASS64=0).
+#ifndef SDV_RES_PASS64
+#define SDV_RES_PASS64 1
+#endif
+
 namespace {
 
 SDV_DEVICE float geglu_gate_f(float x) { return SDV_GELU_FAST ? gelu_erf_fast_f(x) : gelu_erf_f(x); }
@@ -50,7 +57,8 @@ SDV_DEVICE float geglu_gate_f(float x) { return SDV_GELU_FAST ? gelu_erf_fast_f(
 // the MIDDLE of a tile's MFMAs (fragments of the second k-step are already in registers), and the DMA issue and every
 // fragment read are slotted behind MFMAs instead of in front of them.
 // FEAT compiles ONE of the LayerNorm-fold features into the epilogue (dense GEMMs of the transformer blocks only - each costs
-// registers the 256-row tiles do not have to spare): 1 = ln_side 1 consumer, 2 = ln_side 2 consumer, 3 = stats_out producer.
+// registers the 256-row tiles do not have to spare): 1 = ln_side 1 consumer, 2 = ln_side 2 consumer, 3 = stats_out producer,
+// 4 = gn_out producer (GroupNorm statistics of the stored tile; the 4-wave tiles carry that inside FEAT 0 - they have the registers).
 template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST = 2, int FEAT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * WM * WN / 4)) void igemm_kernel(const sdv_gemm_args p) {
     constexpr int NWV = WM * WN;            // waves per workgroup (4 or 8)
@@ -793,7 +801,6 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             typedef unsigned int __attribute__((ext_vector_type(2), may_alias)) slab_u2;
             char* const stg_region = !PERSIST ? smem : (RING ? smem + cb_stage * SLOT : smem + ((slot0 + nkt - 1) & 1) * SLOT);
             char* const slab0 = stg_region + wave * (DBL ? 2 : 1) * SLAB;
-            auto slab_of = [&](int pi) { return slab0 + (DBL ? (pi & 1) * SLAB : 0); };
             // Per-column epilogue vectors of this tile's BN columns, staged in LDS ONCE per tile (their own region behind the
             // K-slab buffers): bias, the LayerNorm-fold row sums s (ln_side 1) or the per-column (mean, rstd) (ln_side 2).
             float* vbias = (float*)(smem + NST * SLOT);
@@ -827,29 +834,38 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             {
                 // (one element per thread - BN <= 512 - so that the global loads are all issued BEFORE the wait below and
                 //  their latency overlaps the tail of the prefetch instead of following it)
-                static_assert(BN <= NWV * 64, "one column vector element per thread");
+                constexpr int NV = (BN + NWV * 64 - 1) / (NWV * 64);   // elements per thread (1; 2 for the 4-wave 320-column tile)
                 constexpr int lnsd = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
                 const bool col_bias = bias && p.bias_mode == 1;
-                const int i = tid, n = n0 + tid;
-                const bool live = i < BN && n < p.N;
-                float vb_ = 0.f, vs_ = 0.f;
-                float2 st = make_float2(0.f, 1.f);
-                if (col_bias && live) vb_ = bias[n];
-                if constexpr (lnsd == 1) {
-                    if (live) vs_ = p.ln_s[n];
-                }
-                if constexpr (lnsd == 2) {
-                    if (live) st = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
+                float vb_[NV], vs_[NV];
+                float2 st[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = tid + j * NWV * 64, n = n0 + i;
+                    const bool live = i < BN && n < p.N;
+                    vb_[j] = vs_[j] = 0.f;
+                    st[j] = make_float2(0.f, 1.f);
+                    if (col_bias && live) vb_[j] = bias[n];
+                    if constexpr (lnsd == 1) {
+                        if (live) vs_[j] = p.ln_s[n];
+                    }
+                    if constexpr (lnsd == 2) {
+                        if (live) st[j] = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
+                    }
                 }
                 // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
                 // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
                 // (ring tiles: always - the dead pieces behind a workgroup's last slab must have landed before the staging slot is
                 //  written and before the workgroup gives its LDS back)
                 if (RING || (PERSIST && has_next)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (i < BN) {
-                    vbias[i] = vb_;
-                    if constexpr (lnsd == 1) vaux[i] = vs_;
-                    if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = tid + j * NWV * 64;
+                    if (i < BN) {
+                        vbias[i] = vb_[j];
+                        if constexpr (lnsd == 1) vaux[i] = vs_[j];
+                        if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st[j];
+                    }
                 }
             }
             // (the epilogue barrier - the vectors are staged AND every wave has left the K loop, whose buffers the slabs alias -
@@ -912,11 +928,23 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 constexpr bool F32 = MODE == 1 || MODE == 3;
                 const bool gg = MODE == 2 || (MODE == 3 && geglu);
                 const bool has_r = MODE == 1 || (MODE == 3 && R != nullptr);
-                constexpr int NPT = (MODE == 0 || MODE == 4) ? 2 : (MODE == 2 ? 4 : 1);   // n-tiles per pass
+                // WIDE: the +residual case of the tiles that have two slabs per wave runs 64-column fp32 passes through both of them
+                // as ONE slab (row stride 272 B): 8 lanes then hold one row's 64 columns, and every residual load / store instruction
+                // covers 8 rows x 128 contiguous bytes instead of 16 rows x 64 - whole cache lines on both streams.
+                // (dense GEMMs only: the conv variants keep ~25 more addressing registers alive across the tile boundary and spilled
+                //  380 - 416 B per lane with the wide pass's 32 + 32 read-back / residual registers)
+                constexpr bool WIDE = SDV_RES_PASS64 && MODE == 1 && DBL && TN >= 2 && (!CONV || SDV_RES_PASS64 == 2);
+                constexpr int RS = WIDE ? 272 : 144;                         // slab row stride in bytes
+                constexpr bool TWO_SLABS = DBL && !WIDE;
+                constexpr int NPT = (MODE == 0 || MODE == 4 || WIDE) ? 2 : (MODE == 2 ? 4 : 1);   // n-tiles per pass
                 constexpr int PP = (TN + NPT - 1) / NPT;                    // passes per m-tile
                 constexpr int NP = TM * PP;
-                constexpr int MAXIT = F32 ? 2 : 4;                          // 64-lane iterations of the row-major phase
-                constexpr int DEPTH = (FEAT == 0 || FEAT == 8 || FEAT == 9) ? 2 : 1, RING = DEPTH + 1;   // residual rows are fetched DEPTH passes ahead
+                constexpr int MAXIT = (F32 && !WIDE) ? 2 : 4;               // 64-lane iterations of the row-major phase
+                // residual rows are fetched DEPTH passes ahead (the fold / statistics variants and the wide passes - twice the rows per
+                // pass - have no registers for a second one)
+                constexpr int DEPTH = ((FEAT == 0 || FEAT == 8 || FEAT == 9) && !WIDE) ? 2 : 1, RING = DEPTH + 1;
+                static_assert(!WIDE || 32 * RS <= 2 * SLAB, "the wide fp32 pass must fit the wave's two slabs");
+                auto slab_of = [&](int pi) { return slab0 + (TWO_SLABS ? (pi & 1) * SLAB : 0); };
                 // geometry of pass pi
                 auto p_mt = [&](int pi) { return pi / PP; };
                 auto p_nt0 = [&](int pi) { return (pi % PP) * NPT; };
@@ -968,11 +996,11 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                             quad_vals(gg, nt, mt, q, z, v);
                             const int cl = (gg ? k * 16 : k * 32) + 8 * q + 4 * lhi;   // column inside the pass
                             if constexpr (F32) {
-                                *(slab_u4*)(slab + l31 * 144 + cl * 4) =
+                                *(slab_u4*)(slab + l31 * RS + cl * 4) =
                                     slab_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                             } else {
                                 const slab_u2 pv = slab_u2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                                *(slab_u2*)(slab + l31 * 144 + cl * 2) = pv;
+                                *(slab_u2*)(slab + l31 * RS + cl * 2) = pv;
                             }
                         }
                     }
@@ -988,10 +1016,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         unsigned a, b;
                         item(pi, it, r, cj, a, b);
                         if constexpr (F32) {
-                            rd[it][0] = *(const slab_u4*)(slab + r * 144 + cj * 32);
-                            rd[it][1] = *(const slab_u4*)(slab + r * 144 + cj * 32 + 16);
+                            rd[it][0] = *(const slab_u4*)(slab + r * RS + cj * 32);
+                            rd[it][1] = *(const slab_u4*)(slab + r * RS + cj * 32 + 16);
                         } else {
-                            rd[it][0] = *(const slab_u4*)(slab + r * 144 + cj * 16);
+                            rd[it][0] = *(const slab_u4*)(slab + r * RS + cj * 16);
                         }
                     }
                 };
@@ -1011,60 +1039,71 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 };
                 // GroupNorm statistics of the tile as STORED (sdv_hip.h "gn_out"): per 32-row block and output column the (sum, sumsq)
                 // of the bf16 values, so that the consumer's GroupNorm needs no statistics pass over the tensor.  In the row-major
-                // phase a lane holds 8 columns of one row per item; the rows of a pass sit in the OTHER lanes and items, so the 8
-                // per-lane values of a statistic are reduced across the lanes that share a column group with a transposing
+                // phase a lane holds 8 columns of one row per item; the rows of a pass sit in the OTHER lanes and items, so the 16
+                // per-lane values (8 columns x 2 statistics) are reduced across the lanes that share a column group with a transposing
                 // butterfly: v_permlane32_swap / v_permlane16_swap fold lane bits 5 and 4 and halve the number of live values each
                 // (both results of a swap are used), row_ror DPP adds fold the lane bits left inside a row of 16.  Afterwards lane
-                // (rho0, rho1, column group cj) holds 2 consecutive columns of the statistic: one 8-byte store.
-                constexpr bool GN_OK = FEAT == 0 && (MODE == 0 || MODE == 1 || MODE == 4);
+                // (rho0, rho1, column group cj) holds 4 consecutive columns of ONE statistic: one 16-byte store.  (Reducing one
+                // statistic at a time - 8 -> 4 -> 2 values - was tried for register pressure: 192 B of scratch instead of 164 B.)
+                // (8-wave tiles: compiled into the FEAT 4 variant only, so that the plain kernels - every launch whose consumer is not
+                //  a GroupNorm - keep their registers: with the statistics code inside FEAT 0 the 256 x 320 conv went from 88 to 164 B
+                //  of scratch per lane whether gn_out was set or not)
+                constexpr bool GN_OK = (FEAT == 4 || (FEAT == 0 && NWV == 4)) && (MODE == 0 || MODE == 1 || MODE == 4);
                 const bool gn_on = GN_OK && p.gn_out != nullptr;
                 // The summation tree of a (32-row block, column) entry is the SAME whatever tile and pass width produced it - row bits
                 // 4, 3 (the items: rows r, r+16 first, then r+8), then 2, 1, 0 (the lanes) - so the statistics of a tensor do not
                 // depend on the tile the cost model picked for its producer (batch size, CFG-shared prefix ...).
                 auto gn_reduce_store = [&](int pi, const u32x4_t* pk) {
                     const int cpo = p_oc(pi) >> 3;                                  // lanes per row of the pass: 8 or 4
-                    const int row_first = m0 + wm * TM * 32 + p_mt(pi) * 32;
-                    const int cj = lane_e & 15, c2 = ((lane_e >> 3) & 2) | (lane_e >> 5);      // c2 = 2 * rho0 + rho1
-                    const int col = p_col0(pi) + cj * 8 + 2 * c2;
-                    const bool live = row_first < p.M && cj < cpo && col < ncols_out;
-                    const long long rb = bz * (long long)(p.M >> 5) + (row_first >> 5);
-                    // one statistic at a time (8 values -> 4 -> 2 per lane): half the live registers of doing both together
+                    float cs[8], cq[8];
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        float x[8];
+                    for (int h = 0; h < 4; ++h)
 #pragma unroll
-                        for (int h = 0; h < 4; ++h)
-#pragma unroll
-                            for (int o = 0; o < 2; ++o) {
-                                auto el = [&](int it) { return o ? __uint_as_float(pk[it][h] & 0xffff0000u) : __uint_as_float(pk[it][h] << 16); };
-                                float r;
-                                if (n_iters(pi) >= 4) {            // rows r, r + 8, r + 16, r + 24 of this lane's column
-                                    const float g0 = el(0), g1 = el(1), g2 = el(2), g3 = el(3);
-                                    r = st ? __builtin_fmaf(g2, g2, g0 * g0) + __builtin_fmaf(g3, g3, g1 * g1) : (g0 + g2) + (g1 + g3);
-                                } else {                            // rows r, r + 16
-                                    const float g0 = el(0), g1 = el(1);
-                                    r = st ? __builtin_fmaf(g1, g1, g0 * g0) : g0 + g1;
-                                }
-                                x[2 * h + o] = r;
+                        for (int o = 0; o < 2; ++o) {
+                            auto el = [&](int it) { return o ? __uint_as_float(pk[it][h] & 0xffff0000u) : __uint_as_float(pk[it][h] << 16); };
+                            if (n_iters(pi) >= 4) {            // rows r, r + 8, r + 16, r + 24 of this lane's column
+                                const float g0 = el(0), g1 = el(1), g2 = el(2), g3 = el(3);
+                                cs[2 * h + o] = (g0 + g2) + (g1 + g3);
+                                cq[2 * h + o] = __builtin_fmaf(g2, g2, g0 * g0) + __builtin_fmaf(g3, g3, g1 * g1);
+                            } else {                            // rows r, r + 16
+                                const float g0 = el(0), g1 = el(1);
+                                cs[2 * h + o] = g0 + g1;
+                                cq[2 * h + o] = __builtin_fmaf(g1, g1, g0 * g0);
                             }
-                        // v[4 k + c] = x[2 c + k]: after the two swaps lane (rho0, rho1) holds columns 2 c2, 2 c2 + 1 of its group
-                        float w[4], u[2];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int j0 = 2 * i, j1 = 2 * i + 1;                   // v indices; v[j] = x[2 * (j & 3) + (j >> 2)]
-                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[2 * (j0 & 3) + (j0 >> 2)]),
-                                                                            __float_as_uint(x[2 * (j1 & 3) + (j1 >> 2)]), false, false);
-                            w[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
                         }
+                    // v[4 k + 2 st + ch] = statistic st of column 4 ch + k: after the two swaps lane (rho0 = st, rho1 = ch) holds columns
+                    // 4 ch .. 4 ch + 3 of statistic st in u[0..3]
+                    float v[16];
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * k]), __float_as_uint(w[2 * k + 1]), false, false);
-                            u[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                            u[k] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(u[k]), 0x128, 0xf, 0xf, false));       // row_ror:8
-                            if (cpo == 4)
-                                u[k] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(u[k]), 0x124, 0xf, 0xf, false));   // row_ror:4
-                        }
-                        if (live) *(float2*)(p.gn_out + (rb * 2 + st) * p.gn_ld + col) = make_float2(u[0], u[1]);
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int st = 0; st < 2; ++st)
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch) v[4 * k + 2 * st + ch] = (st ? cq : cs)[4 * ch + k];
+                    float w[8], u[4];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+                        w[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * k]), __float_as_uint(w[2 * k + 1]), false, false);
+                        u[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        u[k] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(u[k]), 0x128, 0xf, 0xf, false));   // row_ror:8
+                        if (cpo == 4)
+                            u[k] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(u[k]), 0x124, 0xf, 0xf, false));   // row_ror:4
+                    }
+                    // lane (rho1 = lane >> 5, rho0 = (lane >> 4) & 1, cj = lane & 15 < cpo): statistic rho0 of columns cj*8 + rho1*4 .. +3
+                    const int row_first = m0 + wm * TM * 32 + p_mt(pi) * 32;
+                    const int cj = lane_e & 15, st = (lane_e >> 4) & 1, ch = lane_e >> 5;
+                    const int col = p_col0(pi) + cj * 8 + ch * 4;
+                    if (row_first < p.M && cj < cpo && col < ncols_out) {
+                        const long long rb = bz * (long long)(p.M >> 5) + (row_first >> 5);
+                        *(float4*)(p.gn_out + (rb * 2 + st) * p.gn_ld + col) = make_float4(u[0], u[1], u[2], u[3]);
                     }
                 };
                 // phase 2b: residual, activation, bf16, one 16-byte store per item (+ the row statistics of the stored values)
@@ -1183,7 +1222,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         if (has_r && pi + DEPTH < NP) load_res(pi + DEPTH);
                     }
                     if (pi + 1 < NP) {
-                        if constexpr (!DBL) lds_fence();   // one slab: the rows of pass pi must have been read before it is re-used
+                        if constexpr (!TWO_SLABS) lds_fence();   // one slab: the rows of pass pi must have been read before it is re-used
                         park(pi + 1);
                     }
                     finish(pi);
@@ -1252,6 +1291,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     }
 
     const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
+    const bool f32_vec_ok = ((p.ldc & 3) == 0) && ((p.sC & 3) == 0) && ((((uintptr_t)p.out_f32) & 15) == 0);
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
@@ -1270,11 +1310,15 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     if (bias && p.bias_mode == 1 && nb + e < p.N) v[e] += bias[nb + e];
                 }
                 if constexpr (XACT) {
-                    if (p.out_mode) {   // fp32 / image output of the Cout <= 4 convolutions (sdv_hip.h "out_mode")
+                    if (p.out_mode) {   // fp32 / image output (sdv_hip.h "out_mode"): the Cout <= 4 convolutions; fp32 scores of the VAE attention
+                        if (p.out_mode == 1 && f32_vec_ok && nb + 3 < p.N) {
+                            *(float4*)(p.out_f32 + bz * p.sC + (long long)m * p.ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+                            continue;
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (nb + e >= p.N) continue;
-                            const long long idx = (long long)m * p.ldc + nb + e;
+                            const long long idx = bz * p.sC + (long long)m * p.ldc + nb + e;
                             float t = v[e];
                             if (p.out_mode == 1) {
                                 p.out_f32[idx] = t;
@@ -1449,6 +1493,14 @@ int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
         }
         SDV_REQUIRE(false, "sdv_gemm_bf16: the LayerNorm fold / row statistics exist for dense GEMMs on tiles 1, 6, 7, 9 only (not combined; column-side fold: 1, 7, 9)");
     }
+    if constexpr (WM * WN == 8) {
+        if (a.gn_out) {   // the 8-wave tiles carry the GroupNorm-statistics epilogue as a variant of its own (FEAT 4)
+            if constexpr (NST == 2)
+                return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 4>(a, stream)
+                                   : launch_igemm_t<WM, WN, TM, TN, BK, true, NST, 4>(a, stream);
+            SDV_REQUIRE(false, "sdv_gemm_bf16: gn_out is not available on the ring tiles (12, 13)");
+        }
+    }
     return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST>(a, stream)
                        : launch_igemm_t<WM, WN, TM, TN, BK, true, NST>(a, stream);
 }
@@ -1489,11 +1541,14 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     SDV_REQUIRE(a.X && a.W && (a.C || a.out_mode), "sdv_gemm_bf16: null operand");
     SDV_REQUIRE(a.out_mode >= 0 && a.out_mode <= 3, "sdv_gemm_bf16: bad out_mode %d", a.out_mode);
     if (a.out_mode) {
-        SDV_REQUIRE(a.N <= 32 && a.ldc >= a.N && !a.R && a.epi == 0 && !a.ln_side && !a.stats_out && a.mode != 4 && a.batch <= 1,
-                    "sdv_gemm_bf16: out_mode is the plain N <= 32 output form (no residual / activation / fold / batch)");
+        // out_mode 1 (fp32 output) takes any N and a batch (stride sC, in fp32 elements): the VAE attention's scores leave the
+        // accumulators unrounded; the image forms (2, 3) are the N <= 32 output convolutions
+        SDV_REQUIRE(a.ldc >= a.N && !a.R && a.epi == 0 && !a.ln_side && !a.stats_out && a.mode != 4 && !a.gn_out,
+                    "sdv_gemm_bf16: out_mode is a plain output form (no residual / activation / fold / statistics)");
+        SDV_REQUIRE(a.out_mode == 1 || (a.N <= 32 && a.batch <= 1), "sdv_gemm_bf16: the image output forms take N <= 32 and no batch");
         SDV_REQUIRE(a.out_mode == 1 ? a.out_f32 != nullptr : (a.out_f32 || a.out_u8), "sdv_gemm_bf16: out_mode %d without an output", a.out_mode);
         SDV_REQUIRE(a.tile == 0 || (a.tile >= 1 && a.tile <= 4) || a.tile == 10 || a.tile == 11, "sdv_gemm_bf16: out_mode exists in the 4-wave tiles only");
-        if (a.tile == 0) a.tile = 10;   // 256 x 32: one 32-column MFMA tile holds all the outputs
+        if (a.tile == 0) a.tile = a.N <= 32 ? 10 : (a.N <= 64 ? 11 : 4);   // 256 x 32: one 32-column MFMA tile holds all the outputs; wide: 256 x 128
     }
     SDV_REQUIRE(a.k_order >= -1 && a.k_order <= 1, "sdv_gemm_bf16: bad k_order %d", a.k_order);
     if (a.k_order < 0) a.k_order = kDefaultConvKOrder;
@@ -1582,7 +1637,9 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         // The 8-wave 256-row tiles move the fewest L2->LDS bytes per MFMA (the 128x128 tile saturates L2 bandwidth
         // near 0.9 PF/s) but quantise badly on the low-resolution levels, where the small tiles win.
         // (Measured and rejected: 32-wide K tiles with two workgroups per CU - slower than one big workgroup on
-        //  every UNet shape, short K included; profiles/round1_tile_sweep_nimg64.txt.)
+        //  every UNet shape, short K included; profiles/round1_tile_sweep_nimg64.txt.  Re-measured in round 4 with the persistent
+        //  256 x 320 tile as the baseline - 128 x 320 x 32 tiles, two workgroups per CU, 4 or 8 waves each: 0.35 - 0.75x on all 15
+        //  transformer shapes; profiles/round4_two_workgroups_per_cu.txt.)
         struct Cand { int id, bm, bn; float rate; };
         static const Cand cands[] = {{6, 256, 320, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
                                      {1, 128, 128, 3.4f}, {2, 128, 64, 2.4f}, {3, 64, 64, 2.0f}};

@@ -638,16 +638,20 @@ class VAEDecoderEngine:
         hip.gemm(self.a_wv, n, vt, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=HW, bias=self.a_bv, bias_mode=2, batch=nimg,
                  sX=0, sW=HW * C, sC=C * HW)                                         # V^T (+ bias per channel)
         o = torch.empty((nimg * HW, C), dtype=BF16, device=x.device)
-        # The one place a score matrix is materialised (1 head x 512 channels: the flash kernel has no dh = 512 instance): in
-        # chunks of images whose [HW, HW] bf16 scores stay under 512 MiB - 128 frames used to allocate 4.3 GB in one piece
-        per = max(1, self.score_chunk_bytes // (2 * HW * HW))
-        s = torch.empty((min(per, nimg), HW, HW), dtype=BF16, device=x.device)
+        # The one place a score matrix is materialised (1 head x 512 channels: the flash kernel has no dh = 512 instance - 128 Q
+        # registers + 256 accumulators per 32 queries).  The scores leave the Q K^T GEMM as fp32 (out_mode 1) and are rounded ONCE,
+        # as probabilities, by the softmax - what the flash kernels do in registers; rounds 1-3 stored them as bf16 first and this
+        # was the weakest block of the decoder.  Chunks of images whose fp32 scores + bf16 probabilities stay under 512 MiB.
+        per = max(1, self.score_chunk_bytes // (6 * HW * HW))
+        s = torch.empty((min(per, nimg), HW, HW), dtype=F32, device=x.device)
+        pr = torch.empty((min(per, nimg), HW, HW), dtype=BF16, device=x.device)
         for i0 in range(0, nimg, per):
             nb = min(per, nimg - i0)
-            hip.gemm(qk, qk, s, M=HW, N=HW, K=C, ldx=2 * C, ldw=2 * C, ldc=HW, alpha=C ** -0.5, batch=nb,
-                     sX=HW * 2 * C, sW=HW * 2 * C, sC=HW * HW, x_off=i0 * HW * 2 * C, w_off=i0 * HW * 2 * C + C)   # S = Q K^T / sqrt(C)
-            hip.softmax_rows_(s, nb * HW, HW, HW)
-            hip.gemm(s, vt, o, M=HW, N=C, K=HW, ldx=HW, ldw=HW, ldc=C, batch=nb, sX=HW * HW, sW=C * HW, sC=HW * C,
+            hip.gemm(qk, qk, None, M=HW, N=HW, K=C, ldx=2 * C, ldw=2 * C, ldc=HW, alpha=C ** -0.5, batch=nb,
+                     sX=HW * 2 * C, sW=HW * 2 * C, sC=HW * HW, x_off=i0 * HW * 2 * C, w_off=i0 * HW * 2 * C + C,
+                     out_mode=1, out_f32=s)                                          # S = Q K^T / sqrt(C), fp32
+            hip.softmax_rows_f32(s, pr, nb * HW, HW, HW, HW)
+            hip.gemm(pr, vt, o, M=HW, N=C, K=HW, ldx=HW, ldw=HW, ldc=C, batch=nb, sX=HW * HW, sW=C * HW, sC=HW * C,
                      w_off=i0 * C * HW, out_off=i0 * HW * C)
         return hip.linear(o, self.a_wo, self.a_bo, residual=x, gn_hw=HW)
 

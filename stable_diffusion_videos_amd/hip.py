@@ -42,7 +42,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 8     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 9     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -56,6 +56,7 @@ _SIGNATURES = {
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdv_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_groupnorm_finalize": (C.c_int, ([C.c_void_p] + [C.c_int32] * 4 + [C.c_int64]) * 2 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
@@ -479,6 +480,21 @@ _k_softmax_rows = _defop("k_softmax_rows_(Tensor(a!) s, int rows, int cols, int 
 
 def softmax_rows_(s: torch.Tensor, rows: int, cols: int, ld: int):
     _k_softmax_rows(s, rows, cols, ld)
+
+
+def _softmax_rows_f32_impl(s, p, rows, cols, lds, ldp):
+    lib = load()
+    _launch("softmax_rows", dict(bytes=(2 * 4.0 + 2.0) * rows * cols),
+            lambda: _check(lib.sdv_softmax_rows_f32(_ptr(s, F32, "S"), _ptr(p, BF16, "P"), rows, cols, lds, ldp, _stream()),
+                           "sdv_softmax_rows_f32"))
+
+
+_k_softmax_rows_f32 = _defop("k_softmax_rows_f32(Tensor s, Tensor(a!) p, int rows, int cols, int lds, int ldp) -> ()", _softmax_rows_f32_impl)
+
+
+def softmax_rows_f32(s: torch.Tensor, p: torch.Tensor, rows: int, cols: int, lds: int, ldp: int):
+    """bf16 probabilities ``p`` = softmax over each fp32 row of ``s`` (``torch.ops.sdv.k_softmax_rows_f32``)."""
+    _k_softmax_rows_f32(s, p, rows, cols, lds, ldp)
 
 
 def gn_splits(HW: int) -> int:

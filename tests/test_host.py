@@ -293,11 +293,11 @@ def test_every_launch_is_a_torch_custom_op(hip):
         assert "import ctypes" not in (ROOT / "stable_diffusion_videos_amd" / mod).read_text(), mod
     x = torch.zeros((64, 64), dtype=torch.bfloat16)
     with pytest.raises(hip.SdvHipError, match="GPU memory"):
-        torch.ops.sdv.k_igemm(x, x, x, None, None, None, None, None, None, None, None, [64, 64, 64, 64, 64, 64] + [0] * 24 + [-1], 1.0, 1e-5, False)
+        torch.ops.sdv.k_igemm(x, x, x, None, None, None, None, None, None, None, None, None, [64, 64, 64, 64, 64, 64] + [0] * 24 + [-1], 1.0, 1e-5, False)
     with torch.device("meta"):
         m = torch.empty((128, 64), dtype=torch.bfloat16)
         ints = [128, 64, 64, 64, 64, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1] + [0] * 13 + [-1]
-        assert torch.ops.sdv.k_igemm(m, m, m, None, None, None, None, None, None, None, None, ints, 1.0, 1e-5, True).shape == (128, 2)
+        assert torch.ops.sdv.k_igemm(m, m, m, None, None, None, None, None, None, None, None, None, ints, 1.0, 1e-5, True).shape == (128, 2)
         assert torch.ops.sdv.k_slerp_stats(m.float(), m.float()).dtype == torch.float64
 
 
@@ -484,15 +484,23 @@ def test_hot_kernels_do_not_spill():
         names = re.findall(r"Function Name: (\S+)", r.stderr)
         scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
         assert names and len(names) == len(scratch)
-        # (the persistent ring tiles - <.., 32, .., 4, ..>: BK 32, 4 slots - are selectable but never picked by the cost model
-        #  (profiles/round3_ring_ab_nimg256.txt); their LayerNorm-fold epilogue may park up to 192 B, none of it inside the K loop)
-        ring = re.compile(r"igemm_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi32ELb[01]ELi4E")
-        # (the block-scaled fp8 variants - FEAT 9 - of the 256 x 320 tile: their operands are aligned 8-register tuples, and at
-        #  the tile boundary - next tile's addressing + the last slab's fragments + 160 accumulators - the allocator parks two to
-        #  three accumulator tiles in scratch (160 / 176 B); the steady-state K loop has no scratch access, checked on the ISA below)
-        mx = re.compile(r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb[01]ELi2ELi9E")
-        worst = max((sc - (64 if ring.search(n) else 0) - (64 if mx.search(n) else 0), n) for sc, n in zip(scratch, names))
-        assert worst[0] <= limit, f"{name}: kernel {worst[1]} uses {worst[0]} B of scratch per lane over budget (limit {limit})"
+        # Kernels allowed MORE than the file's budget, each with the exact number of bytes measured when it was admitted (so that a
+        # regression inside an exception still fails) - all of them tile-boundary slots, none inside a K loop (ISA lint below):
+        #  * the block-scaled fp8 variants (FEAT 9) of the 256 x 320 tile: operands are aligned 8-register tuples, and at the tile
+        #    boundary the allocator parks two to three accumulator tiles;
+        #  * the GroupNorm-statistics variant (FEAT 4) of the 256 x 320 conv: the statistics butterfly's 16 + 16 values on top of the
+        #    conv's addressing state (the statistics live in a variant of their own so that the plain kernels do not pay for them).
+        exact = {r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb0ELi2ELi9E": 160, r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi9E": 176,
+                 r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi4E": 140}
+
+        def allowed(n):
+            for pat, nbytes in exact.items():
+                if re.search(pat, n):
+                    return nbytes
+            return limit
+
+        over = [(sc, allowed(n), n) for sc, n in zip(scratch, names) if sc > allowed(n)]
+        assert not over, f"{name}: scratch per lane over budget (bytes, allowed, kernel): {over}"
 
 
 def test_buffer_stores_are_followed_by_idle_slots_before_their_registers_change():

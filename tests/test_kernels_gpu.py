@@ -605,6 +605,28 @@ def test_softmax_rows(hip, dev):
     assert rel_l2(sb.float(), torch.softmax(s, -1)) < 4e-3
 
 
+def test_softmax_rows_f32_and_fp32_scores(hip, dev):
+    """The VAE mid-block attention's score path: Q K^T leaves the igemm as fp32 (out_mode 1, any N, batched) - within fp32
+    summation error of a float64 product, i.e. NOT rounded to bf16 - and sdv_softmax_rows_f32 turns the fp32 rows into bf16
+    probabilities rounded once (half a bf16 ulp of the float64 softmax of the same fp32 scores, + the fast exponential)."""
+    nb, HW, C = 3, 256, 128
+    qk = rnd((nb * HW, 2 * C), dev, 47).to(BF16)
+    s = torch.full((nb, HW, HW), float("nan"), dtype=torch.float32, device=dev)
+    hip.gemm(qk, qk, None, M=HW, N=HW, K=C, ldx=2 * C, ldw=2 * C, ldc=HW, alpha=C ** -0.5, batch=nb, sX=HW * 2 * C, sW=HW * 2 * C,
+             sC=HW * HW, w_off=C, out_mode=1, out_f32=s)
+    q, k = qk.view(nb, HW, 2 * C)[..., :C].double(), qk.view(nb, HW, 2 * C)[..., C:].double()
+    ref = torch.einsum("bqc,bkc->bqk", q, k) * C ** -0.5
+    mag = torch.einsum("bqc,bkc->bqk", q.abs(), k.abs()) * C ** -0.5
+    assert float(((s.double() - ref).abs() / mag).max()) < 1e-5                      # bf16 storage would show 2e-3 here
+    p = torch.empty((nb * HW, HW), dtype=BF16, device=dev)
+    hip.softmax_rows_f32(s, p, nb * HW, HW, HW, HW)
+    pref = torch.softmax(s.double().view(nb * HW, HW) , -1)
+    ulp = torch.exp2(torch.floor(torch.log2(pref.clamp_min(1e-30))) - 7)
+    assert float(((p.double() - pref).abs() / (0.5 * ulp + 1e-6 * pref)).max()) <= 1.05
+    with pytest.raises(hip.SdvHipError, match="image output forms"):
+        hip.gemm(qk, qk, None, M=HW, N=HW, K=C, ldx=2 * C, ldw=2 * C, ldc=HW, out_mode=2, out_f32=s)
+
+
 # ------------------------------------------------------------------------------------------------
 # norms
 # ------------------------------------------------------------------------------------------------

@@ -10,7 +10,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stable_diffusion_videos_amd import hip  # noqa: E402
 
-NAMES = {0: "start", 1: "setup done", 2: "K loop done", 5: "epi: vectors staged", 3: "epi: barrier passed", 4: "epi done"}
+NAMES = {0: "start", 1: "setup done", 2: "K loop done", 5: "epi: vectors staged", 3: "epi: barrier passed", 4: "epi done",
+         6: "slab: barrier passed", 7: "slab: next issued", 8: "slab: MFMAs issued", 9: "slab: next landed",
+         10: "last slab: barrier passed", 11: "last slab: next tile issued", 12: "last slab: MFMAs issued"}
 
 
 def main():

@@ -39,6 +39,13 @@ PATCHES = [
      "                if constexpr (FEAT == 3) rowacc[lane_e] = 0.f;\n"),
     ("        kloop();\n", "        SDV_STAMP(1);\n        kloop();\n        SDV_STAMP(2);\n"),
     ("        epilogue();\n", "        epilogue();\n        SDV_STAMP(4);\n"),
+    # fine stamps inside the double-buffered K loop: 6 = barrier passed, 7 = next slab's pieces issued, 8 = slab's MFMAs issued,
+    # 9 = next slab landed (vmcnt(0)); 10 / 11 / 12 = the last slab: barrier passed / next tile set up + its first slab issued / MFMAs issued
+    ("        lds_barrier();\n        stage((slot0 + kt + 1) & 1);\n        compute((slot0 + kt) & 1);\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n",
+     "        lds_barrier();\n        SDV_STAMP(6);\n        stage((slot0 + kt + 1) & 1);\n        SDV_STAMP(7);\n        compute((slot0 + kt) & 1);\n        SDV_STAMP(8);\n"
+     "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        SDV_STAMP(9);\n"),
+    ("    lds_barrier();\n    if (PERSIST && has_next) {\n", "    lds_barrier();\n    SDV_STAMP(10);\n    if (PERSIST && has_next) {\n"),
+    ("    compute((slot0 + nkt - 1) & 1);\n    }\n    };\n", "    SDV_STAMP(11);\n    compute((slot0 + nkt - 1) & 1);\n    SDV_STAMP(12);\n    }\n    };\n"),
     ('extern "C" int sdv_gemm_set_persistent(int on) {', ENTRY + 'extern "C" int sdv_gemm_set_persistent(int on) {'),
 ]
 
