@@ -208,6 +208,11 @@ int sdv_groupnorm_apply_fp8(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, i
                             int32_t HW, int32_t groups, int32_t splits, const float* partials,
                             const float* gamma, const float* beta, float eps, int32_t silu, uint8_t* Y8,
                             float q_scale, void* stream);
+/* Debug aid for the fp8 path (BASELINE.json configs[4]): while `counter` (one device int32, or NULL = off, the default) is set,
+ * every sdv_groupnorm_apply_fp8 launch adds the number of elements whose scaled value fell outside +-448 - i.e. that the e4m3
+ * conversion clamped - to it.  A pilot calibration that is too tight for the prompts actually run then reads non-zero instead of
+ * clipping silently.  Set it before a step is captured into a hipGraph (the pointer is a kernel argument). */
+int sdv_groupnorm_fp8_set_saturation_counter(int32_t* counter);
 
 /* LayerNorm over the last dim of [rows][C] bf16 (BasicTransformerBlock.norm1/2/3) */
 int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta, float eps, int64_t rows,

@@ -120,12 +120,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
                                                        const float* __restrict__ partials,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, int silu, int pix_per_block,
-                                                       uint16_t* __restrict__ Y, float q_scale) {
+                                                       uint16_t* __restrict__ Y, float q_scale, int* __restrict__ sat) {
+    // `sat` (debug, sdv_groupnorm_fp8_set_saturation_counter): number of elements the e4m3 conversion had to clamp - a calibration
+    // that is too tight for the prompts actually run shows up here instead of as silently clipped activations
+    int nsat = 0;
     auto put = [&](long long pix, int c0, const float* f) {
-        if constexpr (FP8OUT)
+        if constexpr (FP8OUT) {
+            if (sat) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) nsat += fabsf(f[e] * q_scale) > 448.f ? 1 : 0;
+            }
             *(uint2*)((uint8_t*)Y + pix * C1 + pix * C2 + c0) = pack8_fp8(f, q_scale);
-        else
+        } else {
             *(bf16x8_raw*)(Y + pix * (C1 + C2) + c0) = pack8(f);
+        }
     };
     __shared__ float gmean[64], grstd[64];
     const int C = C1 + C2;
@@ -194,6 +202,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
             }
             put(pix, c0, f);
         }
+    }
+    if constexpr (FP8OUT) {
+        if (sat && nsat) atomicAdd(sat, nsat);   // (never taken on a calibrated model: no atomic traffic in the normal case)
     }
 }
 
@@ -414,6 +425,14 @@ extern "C" int sdv_groupnorm_stats(const sdv_bf16* X, const sdv_bf16* X2, int32_
     return SDV_OK;
 }
 
+// debug counter of clamped e4m3 conversions (one process drives one GPU; the pointer is baked into captured graphs like every other
+// kernel argument, so it has to be set before a step is captured)
+static int* g_fp8_sat_counter = nullptr;
+extern "C" int sdv_groupnorm_fp8_set_saturation_counter(int32_t* counter) {
+    g_fp8_sat_counter = counter;
+    return SDV_OK;
+}
+
 static int gn_apply_launch(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, int32_t C2, int32_t nimg, int32_t HW,
                            int32_t groups, int32_t splits, const float* partials, const float* gamma, const float* beta,
                            float eps, int32_t silu, void* Y, bool fp8, float q_scale, void* stream) {
@@ -432,10 +451,10 @@ static int gn_apply_launch(const sdv_bf16* X, const sdv_bf16* X2, int32_t C1, in
     const int nblk = (HW + ppb - 1) / ppb;
     if (fp8)
         hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nblk, nimg), dim3(256), 0, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,
-                           groups, splits, partials, gamma, beta, eps, silu, ppb, (uint16_t*)Y, q_scale);
+                           groups, splits, partials, gamma, beta, eps, silu, ppb, (uint16_t*)Y, q_scale, g_fp8_sat_counter);
     else
         hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nblk, nimg), dim3(256), 0, (hipStream_t)stream, X, X2 ? X2 : X, C1, C2, HW,
-                           groups, splits, partials, gamma, beta, eps, silu, ppb, (uint16_t*)Y, 1.0f);
+                           groups, splits, partials, gamma, beta, eps, silu, ppb, (uint16_t*)Y, 1.0f, (int*)nullptr);
     SDV_CHECK_LAUNCH("sdv_groupnorm_apply");
     return SDV_OK;
 }

@@ -63,6 +63,7 @@ _SIGNATURES = {
                             [C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "sdv_groupnorm_apply_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 3 +
                                 [C.c_float, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]),
+    "sdv_groupnorm_fp8_set_saturation_counter": (C.c_int, [C.c_void_p]),
     "sdv_layernorm_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sdv_conv3x3_cin_small": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
     "sdv_im2col3x3_c4": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
@@ -463,6 +464,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     """softmax(Q K^T scale) V (``torch.ops.sdv.k_attention``).  ``q_prescaled``: Q already holds q * scale * log2(e)
     (``LOG2E_SCALE(dh)`` applied as the ``alpha`` of its projection GEMM, one bf16 rounding in total) and ``scale`` is ignored."""
     _k_attention(q, k, vt, out, [B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off], float(scale), bool(causal), bool(q_prescaled))
+
+
+def _fp8_saturation_counter_impl(counter: Optional[torch.Tensor]):
+    if counter is not None and (counter.dtype != torch.int32 or not counter.is_cuda or counter.numel() != 1):
+        raise SdvHipError("fp8 saturation counter: one int32 element in GPU memory")
+    _check(load().sdv_groupnorm_fp8_set_saturation_counter(counter.data_ptr() if counter is not None else None),
+           "sdv_groupnorm_fp8_set_saturation_counter")
+
+
+def set_fp8_saturation_counter(counter: Optional[torch.Tensor]):
+    """Debug aid of the fp8 path: while a one-element int32 device tensor is registered, every e4m3 GroupNorm apply adds the number
+    of elements it had to clamp at +-448 to it (None switches it off).  Register it before a step is captured into a hipGraph."""
+    _fp8_saturation_counter_impl(counter)
 
 
 def q_prescale(dh: int) -> float:

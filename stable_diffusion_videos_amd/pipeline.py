@@ -344,18 +344,46 @@ class StableDiffusionWalkPipeline:
             r.bias_table = t
         return key, coefs, len(ts)
 
-    def _calibrate_fp8(self, h: int, w: int, coefs, nsteps: int, guidance: float, cfg: bool):
+    def enable_fp8_saturation_check(self, on: bool = True):
+        """Debug aid of the fp8 path: count the activations the e4m3 conversion clamps at +-448 (a calibration that is too tight
+        for the prompts actually run).  Call before the first frame is generated - captured step graphs bake the counter's
+        address in; ``fp8_saturated()`` reads it."""
+        if on:
+            self._fp8_sat = torch.zeros(1, dtype=torch.int32, device=self.device)
+            hip.set_fp8_saturation_counter(self._fp8_sat)
+        else:
+            hip.set_fp8_saturation_counter(None)
+            self._fp8_sat = None
+            self._graphs.clear()      # (their launches still carry the old counter's address)
+
+    def fp8_saturated(self) -> int:
+        """Clamped e4m3 conversions since ``enable_fp8_saturation_check()`` (host synchronising)."""
+        sat = getattr(self, "_fp8_sat", None)
+        if sat is None:
+            raise hip.SdvHipError("fp8_saturated(): call enable_fp8_saturation_check() first")
+        return int(sat.item())
+
+    def _calibrate_fp8(self, h: int, w: int, coefs, nsteps: int, guidance: float, cfg: bool, cond: Optional[torch.Tensor] = None):
         """fp8 mode: fix the e4m3 activation scales of the UNet's ResBlock convs with ONE pilot denoise run, eager, before any
-        graph is warmed up or captured: one frame of seeded N(0,1) latents (seed 0, CPU generator) under the unconditional
-        context, all ``nsteps`` steps, scales = 2 x the running amax.  The pilot does not depend on the prompts, the batch, the
-        rank or where a resumed walk starts, so every rank and every re-run quantises identically (the scales used
-        to come from the graph warm-up's zero-filled buffers)."""
+        graph is warmed up or captured: one frame of seeded N(0,1) latents (seed 0, CPU generator), all ``nsteps`` steps,
+        scales = 2 x the running amax over BOTH halves of a real guidance pair - the unconditional half under the empty prompt,
+        the conditional half under ``cond`` ([1, L, D]: the embedding of the walk's FIRST prompt, ``walk()`` sets
+        ``_fp8_pilot_cond``; a bare ``__call__`` passes its own first row).  With trained weights the conditional branch is
+        where the large activations are; rounds 2-3 calibrated under the unconditional context only.  The pilot
+        does not depend on the batch, the rank or where a resumed walk starts - every rank embeds the same first prompt - so
+        every rank and every re-run quantises identically (the scales used to come from the graph warm-up's
+        zero-filled buffers).  ``enable_fp8_saturation_check()`` counts what the scales still clip afterwards."""
         C = self.unet.cfg.in_channels
         g = torch.Generator(device="cpu").manual_seed(0)
         lat = torch.randn((1, h, w, C), generator=g, dtype=F32).to(self.device) * self.scheduler.init_noise_sigma
         uncond = self._uncond_embeddings(None, 1)
         nimg = 2 if cfg else 1
-        self.unet.prepare_context(torch.cat([uncond] * nimg))
+        if cond is not None and tuple(cond.shape[1:]) == tuple(uncond.shape[1:]):
+            cond = cond[:1].to(self.device, F32)
+            pilot_ctx = torch.cat([uncond, cond]) if cfg else cond
+        else:
+            pilot_ctx = torch.cat([uncond] * nimg)
+        self.unet.prepare_context(pilot_ctx)
         self.unet.reserve(nimg, h, w)
         x2 = torch.zeros((nimg * h * w, C), dtype=BF16, device=self.device)
         step = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -510,7 +538,9 @@ class StableDiffusionWalkPipeline:
         if not hasattr(self.scheduler, "coefficient_table"):
             eta = 0.0                                                                             # :404-409: DDIM only
         if getattr(self.unet, "fp8", False) and not self.unet.fp8_calibrated:
-            self._calibrate_fp8(h, w, coefs, nsteps, float(guidance_scale), do_cfg)
+            pilot_cond = getattr(self, "_fp8_pilot_cond", None)
+            self._calibrate_fp8(h, w, coefs, nsteps, float(guidance_scale), do_cfg,
+                                cond=pilot_cond if pilot_cond is not None else text_embeddings[:1])
         # A ragged last batch (B frames where a graph for B' > B frames is already captured) is padded with copies of its
         # last frame and replays the big graph: a second capture would own a second multi-GB private pool for one call.
         # Only while the padding is at most a quarter of the big batch - 60 frames replayed as 128 would pay for 128.
@@ -762,6 +792,10 @@ class StableDiffusionWalkPipeline:
             parallel.barrier()      # every rank has looked at the directory before anyone writes new frames
         shares = parallel.partition_frame_list([c["todo"] for c in clips], world_size, rank)
 
+        # fp8 mode: the pilot calibration's conditional half runs under the walk's FIRST prompt on every rank and on every resume
+        # (prompts[0] of prompt_config.json, whatever frames are left to do), so all of them quantise identically
+        if getattr(self, "fp8", False) and not getattr(self.unet, "fp8_calibrated", True):
+            self._fp8_pilot_cond = self.embed_text(prompts[0]).float().contiguous()
         # pass 2: generate this rank's frames
         # this rank's runs of consecutive frames, coalesced per clip: the holes of a resumed clip fill whole batches together
         per_clip: Dict[int, List[int]] = {}

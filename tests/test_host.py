@@ -21,7 +21,7 @@ def test_c_abi_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libsdv_hip.so does not export {name}"
     assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip.load().sdv_abi_version() == hip.ABI_VERSION == 8
+    assert hip.load().sdv_abi_version() == hip.ABI_VERSION == 9
 
 
 def test_gemm_args_struct_matches_header(hip):

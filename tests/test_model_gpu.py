@@ -420,6 +420,8 @@ def test_baseline_config5_fp8_50_steps_vs_golden(hip, dev, tmp_path):
     for mode in ("fp8", "bf16"):
         pipe = StableDiffusionWalkPipeline.from_pretrained("CompVis/stable-diffusion-v1-4", arch="sd14", fp8=mode == "fp8").to(dev)
         assert pipe.use_graphs
+        if mode == "fp8":
+            pipe.enable_fp8_saturation_check()       # count what the e4m3 conversions clamp
         pipe.walk(["a cat", "a dog"], seeds=[42, 1337], num_interpolation_steps=3, output_dir=str(tmp_path), name=mode,
                   batch_size=3, make_video=False)
         frames[mode] = np.stack([np.asarray(Image.open(tmp_path / mode / f"{mode}_000000" / f"frame{k:06d}.png")) for k in range(3)])
@@ -427,9 +429,20 @@ def test_baseline_config5_fp8_50_steps_vs_golden(hip, dev, tmp_path):
             scales = pipe.unet.fp8_scales()
             assert pipe.unet.fp8_calibrated and len(scales) == 22
             assert all(np.isfinite(a) and np.isfinite(b) and a > 1e-4 and b > 1e-4 for a, b in scales)
-            # the pilot is prompt- / batch- / rank-independent: a direct call on different inputs leaves the scales alone
+            # the pilot ran under (empty prompt, the walk's first prompt) with 2 x head-room: nothing was clamped at +-448 in the
+            # pilot itself or in the 3 x 50 captured steps of the walk (hash-tokenised random-init weights: this guards the plumbing -
+            # counter wired into eager AND captured launches, scales cover both guidance halves - not a trained model's outliers)
+            assert pipe.fp8_saturated() == 0
+            # the pilot is batch- / rank-independent: a direct call on different inputs leaves the scales alone
             pipe(prompt="a horse", num_inference_steps=50, height=512, width=512, output_type="numpy_u8")
             assert pipe.unet.fp8_scales() == scales
+            assert pipe.fp8_saturated() == 0
+            # ... and the counter does count: the same call with every activation scale cut to a fiftieth (2 x head-room gone 25 times over) clamps plenty
+            pipe.unet.set_fp8_scales([(a * 0.02, b * 0.02) for a, b in scales])
+            pipe._graphs.clear()                      # (captured launches bake alpha = sx * sw in)
+            pipe(prompt="a horse", num_inference_steps=2, height=512, width=512, output_type="numpy_u8")
+            assert pipe.fp8_saturated() > 0
+            pipe.enable_fp8_saturation_check(False)
         del pipe
         torch.cuda.empty_cache()
 
