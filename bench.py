@@ -332,8 +332,8 @@ def pmc_profile(batch):
     (profiles/round2_pmc_unet_b<batch>.csv, made by tools/pmc_summary.py from `rocprofv3 --pmc ... tools/unet_once.py <batch>`;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns {kernel: {counter: mean per launch}} or {}
     when there is no profile for this batch size."""
-    path = next((p for p in (ROOT / "profiles" / f"round3_pmc_unet_b{batch}.csv", ROOT / "profiles" / f"round2_pmc_unet_b{batch}.csv")
-                 if p.exists()), None)
+    path = next((p for p in (ROOT / "profiles" / f"round4_pmc_unet_b{batch}.csv", ROOT / "profiles" / f"round3_pmc_unet_b{batch}.csv",
+                             ROOT / "profiles" / f"round2_pmc_unet_b{batch}.csv") if p.exists()), None)
     if path is None:
         return {}
     pmc_profile.source = f"profiles/{path.name}"
@@ -346,18 +346,26 @@ def pmc_profile(batch):
     out = {}
     for (k, c), (tot, n) in acc.items():
         out.setdefault(k, {})[c] = tot / max(n, 1)
+        out[k]["_dispatches"] = max(out[k].get("_dispatches", 0), n)
     return out
 
 
 def dominant_kernel_traffic(pmc):
     """HBM-side bytes per launch of the dominant kernel (the 256x320 implicit-GEMM conv), averaged over its launches in
     one UNet forward: FETCH_SIZE [KiB] x 2 (gfx950 correction) + WRITE_SIZE [KiB]."""
-    for k, c in pmc.items():
-        if k.startswith("igemm_kernel<4, 2, 2, 5, 64, true") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return {"kernel": k, "fetch_bytes": round(c["FETCH_SIZE"] * 2 * 1024), "write_bytes": round(c["WRITE_SIZE"] * 1024),
-                    "source": f"{getattr(pmc_profile, 'source', 'profiles/')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                              "COMMITTED profile of the same forward, not collected in this run)"}
-    return None
+    # (since round 4 the tile has two bf16 conv variants - plain, and with the GroupNorm-statistics epilogue: averaged together,
+    #  weighted by their launches)
+    ks = [(k, c) for k, c in pmc.items() if k.startswith("igemm_kernel<4, 2, 2, 5, 64, true, 2, ") and k.rstrip(">")[-1] in "04"
+          and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+    if not ks:
+        return None
+    n = sum(c["_dispatches"] for _, c in ks)
+    fetch = sum(c["FETCH_SIZE"] * c["_dispatches"] for _, c in ks) / n
+    write = sum(c["WRITE_SIZE"] * c["_dispatches"] for _, c in ks) / n
+    return {"kernel": " + ".join(k for k, _ in ks), "launches_in_profile": n, "fetch_bytes": round(fetch * 2 * 1024),
+            "write_bytes": round(write * 1024),
+            "source": f"{getattr(pmc_profile, 'source', 'profiles/')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                      "COMMITTED profile of the same forward, not collected in this run)"}
 
 
 def attention_object(shapes, pmc):
