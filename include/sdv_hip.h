@@ -151,7 +151,9 @@ int sdv_gemm_set_grid_limit(int n);
 /* Tile order of the persistent workgroups (sdv_gemm_args.walk): 0 = strided raster (workgroup b: tiles b, b + grid, ...);
  * S = 1 / 2 / 4: panel walk with S workgroups per M panel.  The walk is used only where it leaves every workgroup the same
  * number of tiles (M panels divisible over the panel slots), otherwise the launch falls back to the strided order.
- * Results are bit-identical either way.  Returns the previous setting. */
+ * Results are bit-identical either way.  Returns the previous setting.  EXPERIMENT (measured +-1.5 %, profiles/
+ * round4_panel_walk_ab.txt): the kernels are built without it unless sdv_gemm.hip is compiled with -DSDV_PANEL_WALK=1 - the setter
+ * then only records the value. */
 int sdv_gemm_set_walk(int s);
 /* partial (sum, sumsq) [rows][slots][2] -> (mean, rstd) [rows][2] over C channels */
 int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, int32_t C, float eps, float* out, void* stream);

@@ -41,6 +41,13 @@
 // +residual epilogue of the tiles with two staging slabs per wave: 1 = 64-column fp32 passes through ONE 8.5 KB slab (32 rows x
 // (256 + 16) bytes) - every residual load and every store then covers 8 rows x 128 B, whole cache lines; 0 = 32-column fp32 passes
 // through two 4.5 KB slabs (16 rows x 64 B per instruction) - kept for A/B builds (tools/ubench/build_variant.py res32 -DSDV_RES_PASS64=0).
+// Panel walk of the persistent tiles (sdv_hip.h "walk").  Measured +-1.5 % per shape and nothing on the forward
+// (profiles/round4_panel_walk_ab.txt) - and its tile-index arithmetic, merely compiled in, cost the 256 x 320 conv 20 B of scratch
+// and 1-2 % (profiles/round4_round3_vs_round4_gemm.txt), so it is compiled OUT by default: sdv_gemm_set_walk() then has no effect.
+// tools/walk_ab.py runs against a -DSDV_PANEL_WALK=1 build (tools/ubench/build_variant.py walk -DSDV_PANEL_WALK=1).
+#ifndef SDV_PANEL_WALK
+#define SDV_PANEL_WALK 0
+#endif
 #ifndef SDV_RES_PASS64
 #define SDV_RES_PASS64 1
 #endif
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     const bool chan_major = CONV && p.k_order == 1 && p.mode != 0;
     auto setup_tile = [&](int vb) {
         int bm, bn, bz;
-        if (PERSIST && p.walk > 0) {
+        if (SDV_PANEL_WALK && PERSIST && p.walk > 0) {
             // PANEL WALK (sdv_hip.h "walk"): a workgroup takes whole M panels and walks `tiles_n / S` N tiles of each back to back,
             // so that from the second N tile on its X panel comes out of the L2 / Infinity Cache it has just been pulled through
             // instead of HBM (the default order only shares a panel between CUs that miss on it at the same time).  XCD x owns a

@@ -4,7 +4,8 @@ an X panel is shared only between the CUs that miss on it at the same moment), S
 tiles_n / S N tiles of ONE M panel back to back: from its second tile on the panel comes out of L2 / Infinity Cache).
 Interleaved rounds in ONE process, median (min..max) per arm, results asserted bit-identical.
 
-usage: python tools/walk_ab.py [nimg] [rounds] [unet]      ("unet": also whole eager UNet forwards per setting, HIP-event totals)
+NEEDS a library built with the walk compiled in: python tools/ubench/build_variant.py walk -DSDV_PANEL_WALK=1, then
+usage: SDV_HIP_LIB=tools/ubench/libsdv_walk.so python tools/walk_ab.py [nimg] [rounds] [unet]      ("unet": also whole eager UNet forwards per setting, HIP-event totals)
 """
 import statistics
 import sys
