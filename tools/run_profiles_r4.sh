@@ -7,7 +7,7 @@ cd $R
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-300 $O/bench.json
 export TMPDIR=/tmp
 cd /tmp
-SDV_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-walk-pass --no-other-configs > $O/kt_bench.json 2> $O/kt.err; echo "kt rc=$?"
+SDV_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-walk-pass --no-other-configs --no-parity-check > $O/kt_bench.json 2> $O/kt.err; echo "kt rc=$?"
 timeout 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/p1 -- python $R/tools/unet_once.py 128 > $O/p1.log 2>&1; echo "p1 rc=$?"
 timeout 400 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -- python $R/tools/unet_once.py 128 > $O/p2.log 2>&1; echo "p2 rc=$?"
 timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/p3 -- python $R/tools/unet_once.py 128 > $O/p3.log 2>&1; echo "p3 rc=$?"
