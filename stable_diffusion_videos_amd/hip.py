@@ -466,11 +466,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     _k_attention(q, k, vt, out, [B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off], float(scale), bool(causal), bool(q_prescaled))
 
 
+_fp8_sat_ref: Optional[torch.Tensor] = None
+
+
 def _fp8_saturation_counter_impl(counter: Optional[torch.Tensor]):
     if counter is not None and (counter.dtype != torch.int32 or not counter.is_cuda or counter.numel() != 1):
         raise SdvHipError("fp8 saturation counter: one int32 element in GPU memory")
     _check(load().sdv_groupnorm_fp8_set_saturation_counter(counter.data_ptr() if counter is not None else None),
            "sdv_groupnorm_fp8_set_saturation_counter")
+    global _fp8_sat_ref
+    _fp8_sat_ref = counter      # the library holds a raw device pointer: keep the tensor alive for as long as it is registered
 
 
 def set_fp8_saturation_counter(counter: Optional[torch.Tensor]):

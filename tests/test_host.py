@@ -490,8 +490,10 @@ def test_hot_kernels_do_not_spill():
         #    boundary the allocator parks two to three accumulator tiles;
         #  * the GroupNorm-statistics variant (FEAT 4) of the 256 x 320 conv: the statistics butterfly's 16 + 16 values on top of the
         #    conv's addressing state (the statistics live in a variant of their own so that the plain kernels do not pay for them).
+        #  * the LayerNorm-fold variant of the persistent ring tile (BK 32, 4 slots; selectable, never picked by the cost model -
+        #    profiles/round3_ring_ab_nimg256.txt).
         exact = {r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb0ELi2ELi9E": 160, r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi9E": 176,
-                 r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi4E": 140}
+                 r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi4E": 140, r"igemm_kernelILi4ELi2ELi2ELi5ELi32ELb0ELi4ELi1E": 140}
 
         def allowed(n):
             for pat, nbytes in exact.items():
