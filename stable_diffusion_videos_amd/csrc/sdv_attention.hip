@@ -20,6 +20,9 @@
 namespace {
 
 constexpr f32x16_t kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifndef SDV_ATTN_SLAB64
+#define SDV_ATTN_SLAB64 0
+#endif
 constexpr float kDefer = 5.0f;  // log2 units: skip the O rescale while the running max moves by < 2^5
 
 template <int DH>
@@ -39,11 +42,21 @@ struct AttnCfg {
     static constexpr int VPT = (VCH + 255) / 256;
 };
 
-template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF, bool PP = false, int NW = 4>
+// RES ("resident K / V^T": the text cross-attention - Lk <= 128 keys, the same K / V^T for every query of a (sample, head)): the
+// workgroup stages BOTH key tiles once and walks kResBlocks query blocks over them; the Q / O slabs get LDS of their own, so a query
+// block needs no barrier at all, and the next block's Q rows are requested while this one computes.  One query block per workgroup
+// (the self-attention form) is a chain of four dependent memory latencies - Q, key tile 0, key tile 1, the stores - for two key
+// tiles of work: 8.7 us per workgroup at four workgroups per CU.
+#ifndef SDV_ATTN_RES_BLOCKS
+#define SDV_ATTN_RES_BLOCKS 8
+#endif
+constexpr int kResBlocks = SDV_ATTN_RES_BLOCKS;
+template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF, bool PP = false, int NW = 4, bool RES = false>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
-                                                        float scale_log2e, int causal, int BH) {
+                                                        float scale_log2e, int flags, int BH) {
+    const int causal = flags & 1;
     // QT = 32-query tiles per wave: the K / V^T fragments read from LDS are reused for QT MFMAs each.
     // NW = waves per workgroup: one staged K / V^T tile serves NW * QT * 32 queries (staging a tile costs ~17 % of the
     //      4-wave kernel's time in VMEM / LDS-write issue, tools/ubench/build_whatif.py variants 4-6).
@@ -67,7 +80,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // DBUF: two K / V^T tile buffers, tile t+1 is written while tile t is consumed -> ONE barrier per tile
     constexpr int KV_BYTES = Cfg::K_BYTES + Cfg::V_BYTES;
-    constexpr int NBUF = DBUF ? 2 : 1;
+    constexpr int NBUF = (DBUF || RES) ? 2 : 1;
+    static_assert(!RES || (!DBUF && !PP && QT == 1), "resident K / V^T: the plain one-query-tile body");
     char* ldsK = smem;
     char* ldsV = smem + Cfg::K_BYTES;
 
@@ -79,54 +93,29 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (8 private L2s).  All
     // query blocks of one (batch, head) stream the SAME K / V^T (655 KB at 64^2), so they are mapped to ONE XCD, back to
     // back: workgroup w -> XCD w & 7, position i = w >> 3 inside it -> head group i / nqb, query block i % nqb.
-    const int nqb = (Lq + 32 * NW * QT - 1) / (32 * NW * QT);
+    // QUERY-MAJOR order (flags bit 1; the text cross-attention, whose 77 keys are no working set at all): an XCD takes whole
+    // (sample, query block) units and runs their H heads back to back.  A token's row interleaves the heads - DH * 2 = 80 bytes each
+    // at dh 40 - so with the head-major order every 128-byte line of Q and of O was pulled through (and partially written from)
+    // up to eight different L2s.
+    const int nqb_all = (Lq + 32 * NW * QT - 1) / (32 * NW * QT);                 // query blocks of one (sample, head)
+    const int nqb = RES ? (nqb_all + kResBlocks - 1) / kResBlocks : nqb_all;      // workgroups per (sample, head)
     const int wg_i = blockIdx.x >> 3;
-    const int bh = (wg_i / nqb) * 8 + (blockIdx.x & 7);
-    if (bh >= BH) return;                     // BH = batch * heads; the grid is padded to 8 head slots per group
-    const int h = bh % H;
-    const int b = bh / H;
-    const int q0 = ((wg_i % nqb) * NW + wave) * (32 * QT);
-
-    // zero the LDS pads once: K columns [DH, DKP) and V^T rows [DH, DVP) are never rewritten
-    for (int i = tid; i < NBUF * KV_BYTES / 16; i += NT) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
-    if constexpr (ONES) {
-        __syncthreads();
-        for (int bf = 0; bf < NBUF; ++bf) {
-            if (tid < 16)   // rows DH (lanes 0-31 hold it in acc register ONES_R) and DH + 4 (lanes 32-63), 64 keys each
-                *(uint4*)(ldsV + bf * KV_BYTES + (DH + 4 * (tid >> 3)) * VROW + (tid & 7) * 16) =
-                    make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
-            if constexpr (PADM)
-                if (tid < 64) *(uint16_t*)(ldsK + bf * KV_BYTES + tid * KROW + DH * 2) = 0x3F80;   // K[key][DH] = 1.0
-        }
+    int h, b, qw;                                                                 // qw: this workgroup's slot among the nqb
+    if (flags & 2) {
+        const int u = (wg_i / H) * 8 + (blockIdx.x & 7);      // unit = (sample, query block [group])
+        if (u * H >= BH * nqb) return;                        // (BH * nqb = units * H; the grid is padded to 8 unit slots)
+        h = wg_i % H;
+        b = u / nqb;
+        qw = u - b * nqb;
+    } else {
+        const int bh = (wg_i / nqb) * 8 + (blockIdx.x & 7);
+        if (bh >= BH) return;                 // BH = batch * heads; the grid is padded to 8 head slots per group
+        h = bh % H;
+        b = bh / H;
+        qw = wg_i % nqb;
     }
-
-    // ---- Q fragments (B operand): lane owns query rows q0 + qt*32 + l31, d = ks*16 + lhi*8 .. +7 ----
-    bf16x8_t qf[QT][DKS];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        int q = q0 + qt * 32 + l31;
-        q = q < Lq ? q : Lq - 1;
-        const uint16_t* qrow = Q + ((long long)b * Lq + q) * ldq + h * DH;
-#pragma unroll
-        for (int ks = 0; ks < DKS; ++ks) {
-            const int d0 = ks * 16 + lhi * 8;
-            if (d0 < DH) {
-                if constexpr (LEAN) {
-                    const u32x4_t raw = *(const u32x4_t*)(qrow + d0);
-                    u32x4_t sc;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        sc[e] = pack_bf16x2(__builtin_bit_cast(float, raw[e] << 16) * scale_log2e,
-                                            __builtin_bit_cast(float, raw[e] & 0xFFFF0000u) * scale_log2e);
-                    qf[qt][ks] = __builtin_bit_cast(bf16x8_t, sc);
-                } else {
-                    qf[qt][ks] = *(const bf16x8_t*)(qrow + d0);
-                }
-            } else {
-                qf[qt][ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-    }
+    const int qb_first = RES ? qw * kResBlocks : qw;
+    const int qb_last = RES ? (qb_first + kResBlocks < nqb_all ? qb_first + kResBlocks : nqb_all) : qb_first + 1;
 
     // ---- register staging of the next K / V^T tile --------------------------------------------
     u32x4_t kreg[KPT], vreg[VPT];
@@ -189,6 +178,139 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         }
     };
 
+    auto init_pads = [&]() {
+        // zero the LDS pads once: K columns [DH, DKP) and V^T rows [DH, DVP) are never rewritten
+        for (int i = tid; i < NBUF * KV_BYTES / 16; i += NT) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+        if constexpr (ONES) {
+            __syncthreads();
+            for (int bf = 0; bf < NBUF; ++bf) {
+                if (tid < 16)   // rows DH (lanes 0-31 hold it in acc register ONES_R) and DH + 4 (lanes 32-63), 64 keys each
+                    *(uint4*)(ldsV + bf * KV_BYTES + (DH + 4 * (tid >> 3)) * VROW + (tid & 7) * 16) =
+                        make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+                if constexpr (PADM)
+                    if (tid < 64) *(uint16_t*)(ldsK + bf * KV_BYTES + tid * KROW + DH * 2) = 0x3F80;   // K[key][DH] = 1.0
+            }
+        }
+
+    };
+    const int ntiles = (Lk + 63) / 64;
+    if constexpr (RES) {
+        // both key tiles -> LDS, ONCE per workgroup (ntiles <= 2: the launcher sends Lk <= 128 here)
+        init_pads();
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            load_tile(t * 64);
+            store_tile(t * KV_BYTES);
+        }
+        __syncthreads();
+    }
+    constexpr int QNI = (32 * Cfg::CPR + 63) / 64;   // 16-byte pieces per lane of a 32-query tile
+    u32x4_t qraw[RES ? QNI : 1];
+    auto load_q_raw = [&](int qblk) {
+        if constexpr (RES) {
+            const int qbase = (qblk * NW + wave) * 32;
+#pragma unroll
+            for (int i = 0; i < QNI; ++i) {
+                const int c = lane + 64 * i;
+                if (c < 32 * Cfg::CPR) {
+                    const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
+                    int q = qbase + row;
+                    q = q < Lq ? q : Lq - 1;
+                    qraw[i] = *(const u32x4_t*)(Q + ((long long)b * Lq + q) * ldq + h * DH + cc * 8);
+                }
+            }
+        }
+    };
+    for (int qb = qb_first; qb < qb_last; ++qb) {
+    const int q0 = (qb * NW + wave) * (32 * QT);
+    // ---- Q fragments (B operand): lane owns query rows q0 + qt*32 + l31, d = ks*16 + lhi*8 .. +7 ----
+    // The rows travel through a WAVE-PRIVATE slab of the (not yet initialised) K / V^T region: loaded so that adjacent lanes hold
+    // adjacent 16-byte pieces of a row (DH / 8 lanes per row, ~13 rows per instruction), read back in the fragment layout.  Loaded
+    // straight in the fragment layout every instruction touched 32 different rows - 16 bytes from each - and so did the stores of the
+    // epilogue: for the text cross-attention (two key tiles per query block) that was HALF the kernel's time (timing-only builds
+    // without the stores / with one row per wave instruction: 0.63 -> 0.45 / 0.48 ms at the 64^2 level, tools/ubench/build_whatif.py 7, 8).
+    constexpr int QROW = DH * 2 + 16;                 // slab row stride (bytes)
+    constexpr int QSLAB = 32 * QROW;                  // one 32-query tile
+    constexpr int QCH = 32 * Cfg::CPR;                // 16-byte pieces of a 32-query tile
+    static_assert(RES || NW * QSLAB <= NBUF * KV_BYTES, "the Q / O slabs alias the K / V^T buffers");
+    // (dh = 64 keeps the direct accesses: the slab code cost it 6 VGPRs - 124 -> 130 - and with them the fourth wave per SIMD;
+    //  -DSDV_ATTN_SLAB64=1 builds it the other way for A/B)
+    constexpr bool SLAB_IO = DH != 64 || SDV_ATTN_SLAB64 || RES;
+    char* const qslab = smem + (RES ? NBUF * KV_BYTES : 0) + wave * QSLAB;     // (RES: the key tiles stay - the slabs sit behind them)
+    bf16x8_t qf[QT][DKS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        if constexpr (!SLAB_IO) {
+            int q = q0 + qt * 32 + l31;
+            q = q < Lq ? q : Lq - 1;
+            const uint16_t* qrow = Q + ((long long)b * Lq + q) * ldq + h * DH;
+#pragma unroll
+            for (int ks = 0; ks < DKS; ++ks) {
+                const int d0 = ks * 16 + lhi * 8;
+                if (d0 < DH) {
+                    const u32x4_t raw = *(const u32x4_t*)(qrow + d0);
+                    if constexpr (LEAN) {
+                        u32x4_t sc;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            sc[e] = pack_bf16x2(__builtin_bit_cast(float, raw[e] << 16) * scale_log2e,
+                                                __builtin_bit_cast(float, raw[e] & 0xFFFF0000u) * scale_log2e);
+                        qf[qt][ks] = __builtin_bit_cast(bf16x8_t, sc);
+                    } else {
+                        qf[qt][ks] = __builtin_bit_cast(bf16x8_t, raw);
+                    }
+                } else {
+                    qf[qt][ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+            continue;
+        }
+        if constexpr (RES) {
+            if (qb == qb_first) load_q_raw(qb);
+#pragma unroll
+            for (int i = 0; i < QNI; ++i) {
+                const int c = lane + 64 * i;
+                if (c < QCH) *(u32x4_t*)(qslab + (c / Cfg::CPR) * QROW + (c % Cfg::CPR) * 16) = qraw[i];
+            }
+            if (qb + 1 < qb_last) load_q_raw(qb + 1);     // in flight beside this block's MFMAs and exponentials
+        } else {
+#pragma unroll 2
+        for (int i = 0; i < (QCH + 63) / 64; ++i) {
+            const int c = lane + 64 * i;
+            if (c < QCH) {
+                const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
+                int q = q0 + qt * 32 + row;
+                q = q < Lq ? q : Lq - 1;
+                *(u32x4_t*)(qslab + row * QROW + cc * 16) = *(const u32x4_t*)(Q + ((long long)b * Lq + q) * ldq + h * DH + cc * 8);
+            }
+        }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a wave's DS ops execute in order; this keeps the compiler in order too)
+#pragma unroll
+        for (int ks = 0; ks < DKS; ++ks) {
+            const int d0 = ks * 16 + lhi * 8;
+            if (d0 < DH) {
+                const u32x4_t raw = *(const u32x4_t*)(qslab + l31 * QROW + d0 * 2);
+                if constexpr (LEAN) {
+                    u32x4_t sc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sc[e] = pack_bf16x2(__builtin_bit_cast(float, raw[e] << 16) * scale_log2e,
+                                            __builtin_bit_cast(float, raw[e] & 0xFFFF0000u) * scale_log2e);
+                    qf[qt][ks] = __builtin_bit_cast(bf16x8_t, sc);
+                } else {
+                    qf[qt][ks] = __builtin_bit_cast(bf16x8_t, raw);
+                }
+            } else {
+                qf[qt][ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next query tile re-uses the slab
+    }
+    if constexpr (!RES) {
+        if constexpr (SLAB_IO) __syncthreads();   // every wave has its Q fragments: the region can be initialised for K / V^T
+        init_pads();
+    }
     f32x16_t o[QT][DVT];
     float m_run[QT], l_run[QT];  // l_run: this lane's partial row sum (its 32 of the 64 keys per tile)
 #pragma unroll
@@ -201,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
             for (int e = 0; e < 16; ++e) o[qt][t][e] = 0.f;
     }
 
-    const int ntiles = (Lk + 63) / 64;
+    if constexpr (!RES) {
     load_tile(0);
     if constexpr (DBUF) {
         __syncthreads();   // pad initialisation visible / ordered before the first tile lands
@@ -209,9 +331,12 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         if (ntiles > 1) load_tile(64);
         __syncthreads();
     }
+    }
     for (int t = 0; t < ntiles; ++t) {
         int boff = 0;
-        if constexpr (DBUF) {
+        if constexpr (RES) {
+            boff = t * KV_BYTES;                      // both tiles are resident: nothing to stage, no barrier
+        } else if constexpr (DBUF) {
             boff = (t & 1) * KV_BYTES;
             if (t + 1 < ntiles) {
                 store_tile(KV_BYTES - boff);          // tile t+1 -> the buffer tile t-1 was read from (barrier below)
@@ -436,7 +561,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         if constexpr (DBUF) __syncthreads();   // tile t+1 visible; everyone is done reading tile t's buffer
     }
 
-    // ---- normalise and store O[q][h*DH + d] ----
+    // ---- normalise and store O[q][h*DH + d]: through the wave's slab, 16 bytes per lane, adjacent lanes in one row ----
+    if constexpr (SLAB_IO && !RES) __syncthreads();   // every wave is done with the last K / V^T tile: the region is the slabs' again
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float l_tot;
@@ -445,23 +571,46 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         else
             l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
         const float inv = 1.0f / l_tot;
-        const int q = q0 + qt * 32 + l31;
-        if (q < Lq) {
-            uint16_t* orow = O + ((long long)b * Lq + q) * ldo + h * DH;
+        if constexpr (!SLAB_IO) {
+            const int q = q0 + qt * 32 + l31;
+            if (q < Lq) {
+                uint16_t* orow = O + ((long long)b * Lq + q) * ldo + h * DH;
 #pragma unroll
-            for (int dt = 0; dt < DVT; ++dt)
+                for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int d = dt * 32 + 8 * g4 + 4 * lhi;
-                    if (d < DH) {
-                        uint2 w;
-                        w.x = pack_bf16x2(o[qt][dt][4 * g4 + 0] * inv, o[qt][dt][4 * g4 + 1] * inv);
-                        w.y = pack_bf16x2(o[qt][dt][4 * g4 + 2] * inv, o[qt][dt][4 * g4 + 3] * inv);
-                        *(uint2*)(orow + d) = w;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int d = dt * 32 + 8 * g4 + 4 * lhi;
+                        if (d < DH) {
+                            uint2 w;
+                            w.x = pack_bf16x2(o[qt][dt][4 * g4 + 0] * inv, o[qt][dt][4 * g4 + 1] * inv);
+                            w.y = pack_bf16x2(o[qt][dt][4 * g4 + 2] * inv, o[qt][dt][4 * g4 + 3] * inv);
+                            *(uint2*)(orow + d) = w;
+                        }
                     }
-                }
+            }
+            continue;
         }
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = dt * 32 + 8 * g4 + 4 * lhi;
+                if (d < DH)
+                    *(u32x2_t*)(qslab + l31 * QROW + d * 2) = u32x2_t{pack_bf16x2(o[qt][dt][4 * g4 + 0] * inv, o[qt][dt][4 * g4 + 1] * inv),
+                                                                     pack_bf16x2(o[qt][dt][4 * g4 + 2] * inv, o[qt][dt][4 * g4 + 3] * inv)};
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 2
+        for (int i = 0; i < (QCH + 63) / 64; ++i) {
+            const int c = lane + 64 * i;
+            const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
+            const int q = q0 + qt * 32 + row;
+            if (c < QCH && q < Lq)
+                *(u32x4_t*)(O + ((long long)b * Lq + q) * ldo + h * DH + cc * 8) = *(const u32x4_t*)(qslab + row * QROW + cc * 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next query tile re-uses the slab
     }
+    }   // query blocks
 }
 
 template <int DH, int QT>
@@ -469,7 +618,9 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
     using Cfg = AttnCfg<DH>;
     const int nqb = (Lq + 128 * QT - 1) / (128 * QT);
-    dim3 grid(nqb * (((B * H + 7) / 8) * 8));             // 1-D over (head group, query block, XCD slot)
+    const bool qmajor = !causal && Lk <= 128;              // (see the kernel: query-major order for the text cross-attention)
+    dim3 grid(qmajor ? (unsigned)(((B * nqb + 7) / 8) * 8 * H) : (unsigned)(nqb * (((B * H + 7) / 8) * 8)));   // 1-D over (head group, query block, XCD slot)
+    const int flags = (causal ? 1 : 0) | (qmajor ? 2 : 0);
     // Variants measured and not shipped (the template flags remain so that a tools build can instantiate them): one barrier per
     // tile with two K / V^T buffers (DBUF) -4 % at dh = 40 (8 more VGPRs -> 3 waves / SIMD), +-0 at dh = 80; no s_setprio
     // around the MFMA blocks (PRIO = false) -1..3 %; 8 waves per workgroup (NW = 8, one staged tile serves 512 queries) +-0.
@@ -479,13 +630,35 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
                                                     //  kernels' own Q scaling then reproduces the bf16 values bit for bit)
 #define SDV_ATTN_LAUNCH(P, L, D) \
     hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, \
-                       causal, B * H)
+                       flags, B * H)
+    if constexpr (QT == 1 && DH <= 80) {   // (dh 160: the resident form needs 276 registers - one wave per SIMD - and is not built)
+    if (qmajor) {
+        // text cross-attention: both key tiles resident, kResBlocks query blocks per workgroup, query-major order
+        const int nwg = (nqb + kResBlocks - 1) / kResBlocks;
+        dim3 grid_r((unsigned)(((B * nwg + 7) / 8) * 8 * H));
+        constexpr int lds_r = 2 * (Cfg::K_BYTES + Cfg::V_BYTES) + 4 * 32 * (DH * 2 + 16);
+        static_assert(lds_r <= 160 * 1024, "resident K / V^T + slabs must fit the LDS");
+        auto kern = attention_kernel<DH, 1, true, lean, false, false, 4, true>;
+        if (lds_r > 64 * 1024) {
+            static unsigned long long attr_set = 0;            // one bit per device
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (!(attr_set & (1ull << dev))) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r);
+                attr_set |= 1ull << dev;
+            }
+        }
+        hipLaunchKernelGGL(kern, grid_r, dim3(256), lds_r, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, flags, B * H);
+        SDV_CHECK_LAUNCH("sdv_attention_bf16");
+        return SDV_OK;
+    }
+    }
     if constexpr (QT == 2) {
         // software-pipelined two-query-tile kernel: dh = 40, full key tiles only, no mask (the 64^2 self-attention; the caller
         // checks).  Two tiles per wave WITHOUT the pipelined body measured -3 % .. +1 % and are not compiled.
         static_assert(DH == 40, "two query tiles per wave exist for dh = 40 only");
         hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq,
-                           ldk, ldv, ldo, sl, causal, B * H);
+                           ldk, ldv, ldo, sl, flags, B * H);
     } else {
         SDV_ATTN_LAUNCH(true, lean, false);
     }
@@ -594,7 +767,8 @@ extern "C" int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sd
     if (q_prescaled) scale = 0.6931471805599453f;   // * log2(e) == 1
     SDV_REQUIRE(Q && K && Vt && O, "sdv_attention_bf16: null pointer");
     SDV_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sdv_attention_bf16: bad shape");
-    SDV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sdv_attention_bf16: unaligned leading dims");
+    SDV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "sdv_attention_bf16: unaligned leading dims");
+    SDV_REQUIRE(((((uintptr_t)Q) | ((uintptr_t)O)) & 15) == 0, "sdv_attention_bf16: Q / O must be 16-byte aligned");
     SDV_REQUIRE(ldv >= ((Lk + 63) / 64) * 64, "sdv_attention_bf16: ldv=%d must cover roundup(Lk=%d, 64)", ldv, Lk);
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {

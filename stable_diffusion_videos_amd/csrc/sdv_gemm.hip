@@ -492,6 +492,34 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             // k-steps of a slab and fallen back to read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per W fragment, the LDS latency of every
             // read exposed (ISA of round 3); here the issue order is pinned by the sched_barriers and every read has AH x TM MFMAs
             // (64 matrix-pipe cycles each pair) to land.  Same accumulation order per output tile: bit-identical results.
+            if constexpr (TM > TN) {
+                // the mirrored form for tiles that are taller than wide per wave (the 320 x 256 tile of the transposed V^T projections:
+                // TM 5, TN 2): the W fragments of a k-step stay, the X fragments rotate - same k order per output tile, same registers
+                constexpr int AH = SDV_BF16_ROT_AH, STEPS = KSTEPS * TM;
+                bf16x8_t wa[2][TN], xq[AH + 1];
+                auto xfrag = [&](int st) __attribute__((always_inline)) {
+                    return *(const bf16x8_t*)(base + (xrow0 + (st % TM) * 32) * ROWB + frag_off[st / TM]);
+                };
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) wa[0][nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[0]);
+#pragma unroll
+                for (int a = 0; a < AH; ++a) xq[a] = xfrag(a);
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const int ks = st / TM, mt = st % TM;
+                    if (st + AH < STEPS) xq[(st + AH) % (AH + 1)] = xfrag(st + AH);
+                    if (mt == (TM - 1 - AH >= 0 ? TM - 1 - AH : 0) && ks + 1 < KSTEPS) {
+#pragma unroll
+                        for (int nt = 0; nt < TN; ++nt)
+                            wa[(ks + 1) & 1][nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[ks + 1]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks & 1][nt], xq[st % (AH + 1)], acc[nt][mt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
             constexpr int AH = SDV_BF16_ROT_AH, STEPS = KSTEPS * TN;
             bf16x8_t xa[2][TM], wq[AH + 1];
             auto wfrag = [&](int st) __attribute__((always_inline)) {
@@ -813,6 +841,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             float* vbias = (float*)(smem + NST * SLOT);
             float* vaux = vbias + BN;            // [BN] (ln_side 1) or [BN][2] (ln_side 2)
             float* rowacc = vbias + 3 * BN + wave * 64;   // FEAT 3: (sum, sumsq) of this wave's 32 rows of the current m-tile
+            // FEAT 2 (column-side fold): the per-ROW operands - s of the row, the row's bias - of the tile's BM rows, staged with the
+            // column vectors and read back per pass: held in registers for all TM m-tiles they spilled 268 B per lane at TM = 5
+            float* rowvec = vbias + 3 * BN;               // [BM][2] (same bytes as rowacc: FEAT 3 and FEAT 2 never meet)
             const int mfirst = m0 < p.M ? m0 : p.M - 1;
             const long long orow0 = out_row(mfirst);
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(C + orow0 * p.ldc), 0, kRecords, 0x00020000);
@@ -827,15 +858,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 ln_row[mt][1] = 1.f;
                 const int mrow = m0 + wm * TM * 32 + mt * 32 + l31;
                 const bool ok = mrow < p.M;
-                bm_[mt] = (bias && p.bias_mode == 2 && ok) ? bias[mrow] : 0.f;
+                bm_[mt] = (FEAT != 2 && bias && p.bias_mode == 2 && ok) ? bias[mrow] : 0.f;
                 if constexpr (FEAT == 1) {
                     if (ok) {
                         const float2 st = *(const float2*)(p.ln_stats + 2 * (bz * p.M + mrow));
                         ln_row[mt][0] = st.x;
                         ln_row[mt][1] = st.y;
                     }
-                } else if constexpr (FEAT == 2) {
-                    if (ok) ln_row[mt][0] = p.ln_s[mrow];
                 }
             }
             {
@@ -860,6 +889,16 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         if (live) st[j] = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
                     }
                 }
+                constexpr int NRV = FEAT == 2 ? (BM + NWV * 64 - 1) / (NWV * 64) : 1;
+                float2 rv_[NRV];
+                if constexpr (FEAT == 2) {
+#pragma unroll
+                    for (int j = 0; j < NRV; ++j) {
+                        const int i = tid + j * NWV * 64, m = m0 + i;
+                        const bool live = i < BM && m < p.M;
+                        rv_[j] = make_float2(live ? p.ln_s[m] : 0.f, (live && bias && p.bias_mode == 2) ? bias[m] : 0.f);
+                    }
+                }
                 // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
                 // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
                 // (ring tiles: always - the dead pieces behind a workgroup's last slab must have landed before the staging slot is
@@ -874,6 +913,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st[j];
                     }
                 }
+                if constexpr (FEAT == 2) {
+#pragma unroll
+                    for (int j = 0; j < NRV; ++j) {
+                        const int i = tid + j * NWV * 64;
+                        if (i < BM) *(float2*)(rowvec + 2 * i) = rv_[j];
+                    }
+                }
             }
             // (the epilogue barrier - the vectors are staged AND every wave has left the K loop, whose buffers the slabs alias -
             //  sits inside run(), behind the first residual loads: their latency overlaps the barrier wait)
@@ -886,6 +932,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             // the 4 values of accumulator quad q of tile (nt, mt) with scale / LayerNorm fold / bias applied (GEGLU: W rows
             // are interleaved [16 value | 16 gate] per 32-row MFMA tile, so quads g and g+2 of a lane hold the value and the
             // gate of the SAME 4 channels -> quad g in {0, 1} yields 4 of the n-tile's 16 output columns)
+            float cur_s = 0.f, cur_b = 0.f;   // FEAT 2: (s, bias) of this lane's row in the m-tile being parked (set by park)
             auto quad_vals = [&](bool gg, int nt, int mt, int q, int z, float* v) {   // z: an opaque 0 (see park)
                 if (gg) {
                     const float ln_mu = ln_row[mt][0], ar = alpha * ln_row[mt][1];
@@ -907,7 +954,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 const int nb = wcol0 + nt * 32 + 8 * q + 4 * lhi;
                 const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
                 const float4 bq = *(const float4*)(vbias + (nb - n0) + z);
-                const float bvv[4] = {bq.x + bm_[mt], bq.y + bm_[mt], bq.z + bm_[mt], bq.w + bm_[mt]};
+                const float brow = ln_side == 2 ? cur_b : bm_[mt];
+                const float bvv[4] = {bq.x + brow, bq.y + brow, bq.z + brow, bq.w + brow};
                 if constexpr (ln_side == 1) {
                     const float4 s4 = *(const float4*)(vaux + (nb - n0) + z);
                     const float sv4[4] = {s4.x, s4.y, s4.z, s4.w};
@@ -919,7 +967,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     const float4 st1 = *(const float4*)(vaux + 2 * (nb - n0 + z) + 4);   //                 nb+2, nb+3
                     const float mu4[4] = {st0.x, st0.z, st1.x, st1.z}, rs4[4] = {st0.y, st0.w, st1.y, st1.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (acc[nt][mt][4 * q + e] - mu4[e] * ln_row[mt][0]) * (rs4[e] * al) + bvv[e];
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[nt][mt][4 * q + e] - mu4[e] * cur_s) * (rs4[e] * al) + bvv[e];
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * q + e] * al + bvv[e];
@@ -992,6 +1040,11 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     //  would otherwise keep the first m-tile's 8 registers per quad alive for the second - they spilled)
                     int z = 0;
                     asm volatile("" : "+v"(z));
+                    if constexpr (FEAT == 2) {
+                        const float2 rv = *(const float2*)(rowvec + 2 * (wm * TM * 32 + mt * 32 + l31 + z));
+                        cur_s = rv.x;
+                        cur_b = rv.y;
+                    }
 #pragma unroll
                     for (int k = 0; k < NPT; ++k) {
                         if (k >= p_cnt(pi)) continue;
@@ -1442,7 +1495,8 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr bool PERSIST = WM * WN == 8 && (NST == 2 || !CONV);      // (see the kernel)
     constexpr int SLABS = (NST > 2 ? 1 : 2) * WM * WN * 32 * 144;      // the epilogue's staging slabs (alias ONE K-slab buffer)
     constexpr int SLOT = PERSIST && SLABS > TILE_BYTES ? SLABS : TILE_BYTES;
-    constexpr int LDS = NST * SLOT + 3 * BN * 4 + WM * WN * 256;       // K-slab buffers + column vectors + row-stat accumulators
+    constexpr int ROWREG = (FEAT == 2 && BM * 8 > WM * WN * 256) ? BM * 8 : WM * WN * 256;   // FEAT 3 row accumulators / FEAT 2 row operands
+    constexpr int LDS = NST * SLOT + 3 * BN * 4 + ROWREG;              // K-slab buffers + column vectors + row-stat accumulators
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static unsigned long long attr_set = 0;   // one bit per device: the attribute belongs to the device's copy of the function
     const unsigned long long dev_bit = 1ull << current_device();
@@ -1648,14 +1702,17 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         //  256 x 320 tile as the baseline - 128 x 320 x 32 tiles, two workgroups per CU, 4 or 8 waves each: 0.35 - 0.75x on all 15
         //  transformer shapes; profiles/round4_two_workgroups_per_cu.txt.)
         struct Cand { int id, bm, bn; float rate; };
-        static const Cand cands[] = {{6, 256, 320, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
+        // (14 = the 256 x 320 tile transposed, 320 rows x 256 columns: the column-side LayerNorm fold's V^T projections have M = the
+        //  channel count - 320 / 640 / 1280 - which 256- and 128-row tiles pad by 20-60 %; it exists for that launch form only)
+        static const Cand cands[] = {{6, 256, 320, 5.0f}, {14, 320, 256, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
                                      {1, 128, 128, 3.4f}, {2, 128, 64, 2.4f}, {3, 64, 64, 2.0f}};
         // (the 4-wave 256x32 / 256x64 tiles 10 / 11 stay selectable but are not candidates: on the RRDBNet convs the
         //  128x64 tile wins or ties everywhere - tools/esrgan_tile_sweep.py, profiles/round1_esrgan.txt)
         double best = 1e300;
         for (const Cand& c : cands) {
             if (a.epi >= 3 && c.id >= 6) continue;   // extended activations exist in the 4-wave tiles only
-            if ((a.ln_side || a.stats_out || a.fp8) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9)) continue;   // LN fold / fp8 tiles
+            if (c.id == 14 && !(a.ln_side == 2 && a.mode == 0 && !a.fp8 && !a.stats_out && a.epi == 0)) continue;
+            if ((a.ln_side || a.stats_out || a.fp8) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9 || c.id == 14)) continue;   // LN fold / fp8 tiles
             if (a.ln_side == 2 && c.id == 6) continue;                                                                   // (no column-side fold there)
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
             const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
@@ -1668,13 +1725,18 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     a.tile = 4;   // the kernel reads `tile` as the raster strip width: 8 x 4 blocks of output tiles per XCD wave (1 / 2 / 4 / 8
                   // measured on the UNet: 120.2 / 118.5 / 118.1 / 118.0 ms per forward, profiles/round2_raster_order.txt)
     {
-        static const int kBN[] = {0, 128, 64, 64, 128, 0, 320, 256, 128, 320, 32, 64, 320, 256};
-        static const int kWN[] = {0, 2, 1, 2, 2, 0, 2, 2, 2, 2, 1, 1, 2, 2};
-        SDV_REQUIRE(tile >= 1 && tile <= 13 && kBN[tile], "sdv_gemm_bf16: bad tile %d", tile);
+        static const int kBN[] = {0, 128, 64, 64, 128, 0, 320, 256, 128, 320, 32, 64, 320, 256, 256};
+        static const int kWN[] = {0, 2, 1, 2, 2, 0, 2, 2, 2, 2, 1, 1, 2, 2, 4};
+        SDV_REQUIRE(tile >= 1 && tile <= 14 && kBN[tile], "sdv_gemm_bf16: bad tile %d", tile);
         a.stats_p = ((a.N + kBN[tile] - 1) / kBN[tile]) * kWN[tile];
     }
     if (plan_only) return a.stats_p;
     SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
+    if (tile == 14) {   // 320 x 256, 8 waves as 2 x 4: dense GEMMs, plain or with the column-side LayerNorm fold (the V^T projections)
+        SDV_REQUIRE(a.mode == 0 && !a.fp8 && !a.stats_out && !a.gn_out && a.ln_side != 1 && a.epi == 0 && !a.out_mode,
+                    "sdv_gemm_bf16: tile 14 (320 x 256) carries the plain and the column-side-fold dense GEMM only");
+        return a.ln_side == 2 ? launch_igemm_t<2, 4, 5, 2, 64, false, 2, 2>(a, s) : launch_igemm_t<2, 4, 5, 2, 64, false, 2, 0>(a, s);
+    }
     SDV_REQUIRE(!(a.epi == 1 && a.R), "sdv_gemm_bf16: GEGLU does not take a residual");
     switch (tile) {
 #ifdef SDV_GEMM_ONLY_TILE6   // (tools: compile the 256 x 320 tile alone for resource / ISA inspection)

@@ -109,7 +109,29 @@ def test_gemm_geglu(hip, dev, tile):
     assert rel_l2(out.float(), ref) < MFMA_TOL
 
 
-@pytest.mark.parametrize("tile", [0, 1, 6, 7, 9, 12])
+@pytest.mark.parametrize("M,C,L,nb", [(320, 320, 4096, 3), (640, 640, 1024, 2), (1280, 1280, 256, 2), (320, 320, 200, 2), (512, 128, 4096, 1)])
+def test_gemm_transposed_tile_320x256(hip, dev, M, C, L, nb):
+    """Tile 14 = the 256 x 320 tile transposed (320 rows x 256 columns, 8 waves as 2 x 4, X fragments rotating): the batched V^T
+    projections (M = channels, N = tokens of one image) without the 20-60 % row padding of the 256- / 128-row tiles.  Plain and
+    with a per-row bias against float64 (half a bf16 ulp + accumulation), ragged N and M, and bit-identical to tile 7."""
+    w = rnd((M, C), dev, 301, C ** -0.5).to(BF16)
+    x = rnd((nb * L, C), dev, 302).to(BF16)
+    bias = rnd((M,), dev, 303)
+    outs = {}
+    for tile in (14, 7):
+        vt = torch.zeros((nb, M, L), dtype=BF16, device=dev)
+        hip.gemm(w, x, vt, M=M, N=L, K=C, ldx=C, ldw=C, ldc=L, batch=nb, sX=0, sW=L * C, sC=M * L, bias=bias, bias_mode=2, tile=tile)
+        outs[tile] = vt
+    torch.cuda.synchronize()
+    ref = torch.einsum("ck,blk->bcl", w.double(), x.double().view(nb, L, C)) + bias.double()[None, :, None]
+    mag = torch.einsum("ck,blk->bcl", w.double().abs(), x.double().abs().view(nb, L, C)) + bias.double().abs()[None, :, None]
+    d = (outs[14].double() - ref).abs()
+    ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+    assert float((d / (0.5 * ulp + 1e-5 * mag)).max()) <= 1.0
+    assert torch.equal(outs[14], outs[7])
+
+
+@pytest.mark.parametrize("tile", [0, 1, 6, 7, 9, 12, 14])
 @pytest.mark.parametrize("M,C,N2", [(512, 320, 640), (300, 640, 1280), (4096, 320, 2560), (100096, 320, 640)])
 def test_gemm_layernorm_fold(hip, dev, tile, M, C, N2):
     """LayerNorm folded into the GEMMs around it (BasicTransformerBlock.norm1/2/3, reached from unet(...) at
@@ -123,6 +145,9 @@ def test_gemm_layernorm_fold(hip, dev, tile, M, C, N2):
     res = bf16_round(res)
     gamma, beta = 1.0 + 0.3 * rnd((C,), dev, 114), 0.2 * rnd((C,), dev, 115)
     # producer: y = x W0^T + b0 + res, plus the statistics of the bf16 rows it wrote
+    col_tile = tile                                               # tile 14 exists for the column-side fold only
+    if tile == 14:
+        tile = 0
     y, st = hip.linear(x.to(BF16), w0.to(BF16), b0, residual=res.to(BF16), want_stats=True, tile=tile)
     yf = y.float()
     mean, var = yf.mean(1), yf.var(1, unbiased=False)
@@ -154,7 +179,7 @@ def test_gemm_layernorm_fold(hip, dev, tile, M, C, N2):
         if tile in (6, 12):      # the 256 x 320 tiles do not carry the column-side fold (it spilled): refused, never picked
             with pytest.raises(hip.SdvHipError):
                 hip.gemm(wvp, y, vt, tile=tile, **kw)
-        hip.gemm(wvp, y, vt, tile=7 if tile in (6, 12) else tile, **kw)
+        hip.gemm(wvp, y, vt, tile=7 if tile in (6, 12) else col_tile, **kw)
         ref = torch.einsum("ck,blk->bcl", wv, ln.view(2, L, C))
         assert rel_l2(vt.float(), ref) < MFMA_TOL
 
@@ -460,7 +485,7 @@ def attn_ref(q, k, v, heads, scale):
 
 
 @pytest.mark.parametrize("dh", [40, 64, 80, 160])
-@pytest.mark.parametrize("Lq,Lk", [(256, 256), (200, 77), (4096, 4096), (64, 100), (4, 4)])
+@pytest.mark.parametrize("Lq,Lk", [(256, 256), (200, 77), (4096, 4096), (64, 100), (4, 4), (1200, 77), (1024, 128)])
 def test_attention(hip, dev, dh, Lq, Lk):
     if Lq == 4096 and dh not in (40, 64):
         pytest.skip("4096-token self-attention only exists at the 40/64-wide heads")

@@ -29,3 +29,21 @@ for qs in qscales:
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
     print(f"qscale={qs} dh={dh} L={L} nimg={nimg}: {ms:.3f} ms  {4.0 * nimg * heads * L * L * dh / ms / 1e9:.0f} TFLOP/s algorithmic")
+# text cross-attention (Lk = 77): Q + O streaming, two key tiles per query block
+for dh, L, heads in ((40, 4096, 8), (80, 1024, 8), (160, 256, 8)):
+    C = dh * heads
+    q = torch.randn((nimg * L, C), device=dev).to(torch.bfloat16)
+    k = torch.randn((nimg * 77, C), device=dev).to(torch.bfloat16)
+    vt = torch.zeros((nimg, C, 128), dtype=torch.bfloat16, device=dev)
+    vt[:, :, :77] = torch.randn((nimg, C, 77), device=dev).to(torch.bfloat16)
+    o = torch.empty((nimg * L, C), dtype=torch.bfloat16, device=dev)
+    fn = lambda: hip.attention(q, k, vt, o, B=nimg, H=heads, Lq=L, Lk=77, dh=dh, ldq=C, ldk=C, ldv=128, ldo=C, scale=dh ** -0.5)
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 5
+    print(f"cross dh={dh} Lq={L} Lk=77 nimg={nimg}: {ms:.3f} ms  {4.0 * nimg * heads * L * 77 * dh / ms / 1e9:.0f} TFLOP/s algorithmic  "
+          f"{2 * 2.0 * nimg * L * C / ms / 1e6:.0f} GB/s of Q + O")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Timing-only variants of the attention kernel: each removes ONE cost from a patched COPY of csrc/sdv_attention.hip (the
 product source carries none of this) - 1 exps, 2 barriers (racy), 3 row max, 4 K/V staging (one tile reused), 5 LDS stores
-only after the first tile, 6 global loads only for the first tile.  Results are wrong by construction.  Builds
+only after the first tile, 6 global loads only for the first tile, 7 no O stores, 8 Q rows broadcast (one address per wave).  Results are wrong by construction.  Builds
 tools/ubench/libsdv_whatif{n}.so with the same C ABI; run e.g.
     SDV_HIP_LIB=tools/ubench/libsdv_whatif1.so python tools/attn_bench.py 64"""
 import subprocess
@@ -32,6 +32,11 @@ PATCHES = {
                "            if (t + 1 < ntiles) load_tile((t + 1) * 64);\n"
                "            if (t + 1 == ntiles) asm volatile(\"\" ::\"v\"(kreg[0]), \"v\"(vreg[0]));\n"),
     6: (STAGE, "            __syncthreads();\n            store_tile(0);\n            __syncthreads();\n"),
+    # 7 / 8 (round 4, the Lk = 77 cross-attention): no O stores (one lane of one block keeps the values alive) / Q rows not loaded
+    # per lane (every lane reads row 0 of its block - one address per wave instruction) - what the 32-rows-per-instruction
+    # MFMA-layout accesses of the prologue and the epilogue cost the texture addresser
+    7: ("                        *(uint2*)(orow + d) = w;", "                        if (q0 < -1) *(uint2*)(orow + d) = w;"),
+    8: ("        int q = q0 + qt * 32 + l31;\n        q = q < Lq ? q : Lq - 1;", "        int q = q0 + qt * 32;\n        q = q < Lq ? q : Lq - 1;"),
 }
 
 b.build()
