@@ -768,6 +768,7 @@ extern "C" int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sd
     SDV_REQUIRE(Q && K && Vt && O, "sdv_attention_bf16: null pointer");
     SDV_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sdv_attention_bf16: bad shape");
     SDV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "sdv_attention_bf16: unaligned leading dims");
+    SDV_REQUIRE(dh == 40 || dh == 64 || dh == 80 || dh == 160, "sdv_attention_bf16: unsupported head dim %d (40/64/80/160)", dh);
     SDV_REQUIRE(((((uintptr_t)Q) | ((uintptr_t)O)) & 15) == 0, "sdv_attention_bf16: Q / O must be 16-byte aligned");
     SDV_REQUIRE(ldv >= ((Lk + 63) / 64) * 64, "sdv_attention_bf16: ldv=%d must cover roundup(Lk=%d, 64)", ldv, Lk);
     hipStream_t s = (hipStream_t)stream;
