@@ -32,11 +32,13 @@ PATCHES = {
                "            if (t + 1 < ntiles) load_tile((t + 1) * 64);\n"
                "            if (t + 1 == ntiles) asm volatile(\"\" ::\"v\"(kreg[0]), \"v\"(vreg[0]));\n"),
     6: (STAGE, "            __syncthreads();\n            store_tile(0);\n            __syncthreads();\n"),
+    # (7 / 8 were measured on the tree BEFORE the Q / O slabs - commit 14d0cf9; in today's source they only touch the direct-access
+    #  path that dh = 64 keeps)
     # 7 / 8 (round 4, the Lk = 77 cross-attention): no O stores (one lane of one block keeps the values alive) / Q rows not loaded
     # per lane (every lane reads row 0 of its block - one address per wave instruction) - what the 32-rows-per-instruction
     # MFMA-layout accesses of the prologue and the epilogue cost the texture addresser
     7: ("                        *(uint2*)(orow + d) = w;", "                        if (q0 < -1) *(uint2*)(orow + d) = w;"),
-    8: ("        int q = q0 + qt * 32 + l31;\n        q = q < Lq ? q : Lq - 1;", "        int q = q0 + qt * 32;\n        q = q < Lq ? q : Lq - 1;"),
+    8: ("            int q = q0 + qt * 32 + l31;\n            q = q < Lq ? q : Lq - 1;", "            int q = q0 + qt * 32;\n            q = q < Lq ? q : Lq - 1;"),
 }
 
 b.build()
