@@ -79,7 +79,7 @@ typedef struct sdv_gemm_args {
     int32_t mode, Hin, Win, Hout, Wout, circular;
     int32_t epi, bias_mode, bias_step_stride;
     int32_t batch;
-    int32_t tile;    /* 12 = 256x320, 13 = 256x256 as a ring of four 32-wide K tiles (counted vmcnt); 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 256x32, 11 = 256x64 (4 waves); 14 = 320x256 (8 waves as 2 x 4: the 256x320 tile transposed, dense GEMMs plain or with the column-side LayerNorm fold - the batched V^T projections, whose M is the channel count) */
+    int32_t tile;    /* 12 = 256x320, 13 = 256x256 as a ring of four 32-wide K tiles (counted vmcnt); 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 256x32, 11 = 256x64 (4 waves); 14 = 320x256 (8 waves as 2 x 4: the 256x320 tile transposed, dense GEMMs plain or with the column-side LayerNorm fold - the batched V^T projections, whose M is the channel count; never picked by tile 0) */
     float alpha;
     uint32_t div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;   /* filled in by sdv_gemm_bf16 (mode 4 row mapping); callers leave 0 */
     int32_t alpha_cols;   /* > 0: alpha multiplies only output columns [0, alpha_cols) (the Q half of a fused [Q | K] projection:

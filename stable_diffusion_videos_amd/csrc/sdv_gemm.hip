@@ -844,6 +844,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             // FEAT 2 (column-side fold): the per-ROW operands - s of the row, the row's bias - of the tile's BM rows, staged with the
             // column vectors and read back per pass: held in registers for all TM m-tiles they spilled 268 B per lane at TM = 5
             float* rowvec = vbias + 3 * BN;               // [BM][2] (same bytes as rowacc: FEAT 3 and FEAT 2 never meet)
+            // (only where TM > 2 - the 320 x 256 tile: the tiles the cost model picks keep the row operands in registers and the
+            //  fold expression exactly as round 3 compiled them, see the note at the candidates list)
+            constexpr bool ROWV = FEAT == 2 && TM > 2;
             const int mfirst = m0 < p.M ? m0 : p.M - 1;
             const long long orow0 = out_row(mfirst);
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(C + orow0 * p.ldc), 0, kRecords, 0x00020000);
@@ -858,13 +861,15 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 ln_row[mt][1] = 1.f;
                 const int mrow = m0 + wm * TM * 32 + mt * 32 + l31;
                 const bool ok = mrow < p.M;
-                bm_[mt] = (FEAT != 2 && bias && p.bias_mode == 2 && ok) ? bias[mrow] : 0.f;
+                bm_[mt] = (!ROWV && bias && p.bias_mode == 2 && ok) ? bias[mrow] : 0.f;
                 if constexpr (FEAT == 1) {
                     if (ok) {
                         const float2 st = *(const float2*)(p.ln_stats + 2 * (bz * p.M + mrow));
                         ln_row[mt][0] = st.x;
                         ln_row[mt][1] = st.y;
                     }
+                } else if constexpr (FEAT == 2 && !ROWV) {
+                    if (ok) ln_row[mt][0] = p.ln_s[mrow];
                 }
             }
             {
@@ -889,9 +894,9 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         if (live) st[j] = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
                     }
                 }
-                constexpr int NRV = FEAT == 2 ? (BM + NWV * 64 - 1) / (NWV * 64) : 1;
+                constexpr int NRV = ROWV ? (BM + NWV * 64 - 1) / (NWV * 64) : 1;
                 float2 rv_[NRV];
-                if constexpr (FEAT == 2) {
+                if constexpr (ROWV) {
 #pragma unroll
                     for (int j = 0; j < NRV; ++j) {
                         const int i = tid + j * NWV * 64, m = m0 + i;
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                         if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st[j];
                     }
                 }
-                if constexpr (FEAT == 2) {
+                if constexpr (ROWV) {
 #pragma unroll
                     for (int j = 0; j < NRV; ++j) {
                         const int i = tid + j * NWV * 64;
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 const int nb = wcol0 + nt * 32 + 8 * q + 4 * lhi;
                 const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
                 const float4 bq = *(const float4*)(vbias + (nb - n0) + z);
-                const float brow = ln_side == 2 ? cur_b : bm_[mt];
+                const float brow = ROWV ? cur_b : bm_[mt];
                 const float bvv[4] = {bq.x + brow, bq.y + brow, bq.z + brow, bq.w + brow};
                 if constexpr (ln_side == 1) {
                     const float4 s4 = *(const float4*)(vaux + (nb - n0) + z);
@@ -967,7 +972,10 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     const float4 st1 = *(const float4*)(vaux + 2 * (nb - n0 + z) + 4);   //                 nb+2, nb+3
                     const float mu4[4] = {st0.x, st0.z, st1.x, st1.z}, rs4[4] = {st0.y, st0.w, st1.y, st1.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (acc[nt][mt][4 * q + e] - mu4[e] * cur_s) * (rs4[e] * al) + bvv[e];
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (ROWV) v[e] = __builtin_fmaf(__builtin_fmaf(-mu4[e], cur_s, acc[nt][mt][4 * q + e]), rs4[e] * al, bvv[e]);
+                        else v[e] = (acc[nt][mt][4 * q + e] - mu4[e] * ln_row[mt][0]) * (rs4[e] * al) + bvv[e];
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * q + e] * al + bvv[e];
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     //  would otherwise keep the first m-tile's 8 registers per quad alive for the second - they spilled)
                     int z = 0;
                     asm volatile("" : "+v"(z));
-                    if constexpr (FEAT == 2) {
+                    if constexpr (ROWV) {
                         const float2 rv = *(const float2*)(rowvec + 2 * (wm * TM * 32 + mt * 32 + l31 + z));
                         cur_s = rv.x;
                         cur_b = rv.y;
@@ -1703,8 +1711,12 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         //  transformer shapes; profiles/round4_two_workgroups_per_cu.txt.)
         struct Cand { int id, bm, bn; float rate; };
         // (14 = the 256 x 320 tile transposed, 320 rows x 256 columns: the column-side LayerNorm fold's V^T projections have M = the
-        //  channel count - 320 / 640 / 1280 - which 256- and 128-row tiles pad by 20-60 %; it exists for that launch form only)
-        static const Cand cands[] = {{6, 256, 320, 5.0f}, {14, 320, 256, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
+        //  channel count - 320 / 640 / 1280 - which 256- and 128-row tiles pad by 20-60 %, and it runs them 1.2 - 1.5x faster
+        //  (profiles/round4_vt_tile_ab.txt).  It is NOT a candidate: picked by batch size like every tile, it broke the batch
+        //  invariance of a frame in bench.py's 50-step parity self-check (uint8 max-abs 4-5 between a frame generated in a batch of
+        //  128 and in a batch of 4) although its outputs equal tile 7's bit for bit on every shape tested - unexplained at the end of
+        //  round 4, so the V^T projections stay on tiles 9 / 7 / 1; tile 14 remains selectable (sdv_gemm_args.tile, SDV_VT_TILE).)
+        static const Cand cands[] = {{6, 256, 320, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
                                      {1, 128, 128, 3.4f}, {2, 128, 64, 2.4f}, {3, 64, 64, 2.0f}};
         // (the 4-wave 256x32 / 256x64 tiles 10 / 11 stay selectable but are not candidates: on the RRDBNet convs the
         //  128x64 tile wins or ties everywhere - tools/esrgan_tile_sweep.py, profiles/round1_esrgan.txt)

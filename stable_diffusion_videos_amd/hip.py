@@ -203,6 +203,9 @@ _GEMM_INTS = ("M", "N", "K", "ldx", "ldw", "ldc", "ldr", "C1", "ldx2", "epi", "m
               "out_mode", "k_order")
 
 
+# Developer knob: tile of the column-side-fold (V^T) launches, 0 = cost model.  FORCE_TILE (the 256 x 320 tile) cannot carry them; they
+# are bit-identical across tiles by construction (explicit FMAs in the fold), which the batch-128 parity checks rely on.
+VT_TILE = int(os.environ.get("SDV_VT_TILE", "0"))
 GN_EPILOGUE = os.environ.get("SDV_GN_EPILOGUE", "1") != "0"     # A/B knob: 0 = every GroupNorm runs its own statistics pass
 
 
@@ -291,6 +294,8 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
     a.batch, a.tile, a.alpha, a.alpha_cols = batch, g["tile"], alpha, g["alpha_cols"]
     if FORCE_TILE and not g["tile"] and not g["out_mode"] and epi < 3 and not (ln_stats is not None and g["ln_side"] == 2):
         a.tile = FORCE_TILE
+    if VT_TILE and not g["tile"] and ln_stats is not None and g["ln_side"] == 2:
+        a.tile = VT_TILE
     if ln_stats is not None:
         a.ln_stats, a.ln_s, a.ln_side = _ptr(ln_stats, F32, "ln_stats"), _ptr(ln_s, F32, "ln_s"), g["ln_side"]
     if gn_out is not None:

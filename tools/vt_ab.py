@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """The transposed V^T projections of the UNet's self-attention (column-side LayerNorm fold, M = channels, N = tokens of one image,
-batch = samples) on the tiles that carry them: 9 (128 x 320), 7 (256 x 256), 14 (320 x 256, round 4) and what the cost model picks.
+batch = samples) on the tiles that carry them: 9 (128 x 320), 7 (256 x 256), 14 (320 x 256, round 4; selectable, not a cost-model
+candidate - DESIGN.md row 2b) and what the cost model picks.
 usage: python tools/vt_ab.py [nimg] [rounds]"""
 import statistics
 import sys
