@@ -454,12 +454,14 @@ class StableDiffusionWalkPipeline:
 
         ent["one_step"] = one_step
         if self.use_graphs:
+            t0 = time.perf_counter()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 one_step()                       # warm-up: lazy allocations / attribute sets happen here
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
             g = torch.cuda.CUDAGraph()
             # with a process group alive its watchdog thread may touch the runtime while this thread captures: only this
             # thread's calls (kernel launches through the C ABI) need to be capture-safe
@@ -467,6 +469,7 @@ class StableDiffusionWalkPipeline:
             with torch.cuda.graph(g, capture_error_mode=mode):
                 one_step()
             ent["graph"] = g
+            self.last_graph_build = {"nimg": nimg, "warmup_s": t1 - t0, "capture_s": time.perf_counter() - t1}
         self._graphs[key] = ent
         return ent
 
