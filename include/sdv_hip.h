@@ -79,7 +79,9 @@ typedef struct sdv_gemm_args {
     int32_t mode, Hin, Win, Hout, Wout, circular;
     int32_t epi, bias_mode, bias_step_stride;
     int32_t batch;
-    int32_t tile;    /* 12 = 256x320, 13 = 256x256 as a ring of four 32-wide K tiles (counted vmcnt); 0 auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128, 9 = 128x320 (8 waves); 10 = 256x32, 11 = 256x64 (4 waves); 14 = 320x256 (8 waves as 2 x 4: the 256x320 tile transposed, dense GEMMs plain or with the column-side LayerNorm fold - the batched V^T projections, whose M is the channel count; never picked by tile 0) */
+    int32_t tile;    /* 0 auto (cost model); 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (4 waves); 6 = 256x320, 7 = 256x256, 8 = 256x128,
+                        9 = 128x320 (8 waves, persistent); 10 = 256x32, 11 = 256x64 (4 waves: the typed-output convolutions).  (12 - 14 of
+                        ABI <= 9 - the LDS-ring tiles and the transposed 320x256 tile - were experiments; gone in ABI 10.) */
     float alpha;
     uint32_t div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;   /* filled in by sdv_gemm_bf16 (mode 4 row mapping); callers leave 0 */
     int32_t alpha_cols;   /* > 0: alpha multiplies only output columns [0, alpha_cols) (the Q half of a fused [Q | K] projection:
@@ -89,8 +91,9 @@ typedef struct sdv_gemm_args {
      * (slots = sdv_gemm_stats_slots(args)), sdv_rowstats_finalize turns them into (mean, rstd) per row, and the CONSUMER
      * runs on the UN-normalised tensor with gamma-scaled weights W' = gamma o W:
      *     LN(x) W^T + b = rstd * (x W'^T - mean * s) + (W beta + b),   s[n] = sum_k W'[n][k]   (pass W beta + b as `bias`)
-     * ln_side 1: ln_stats [batch][M][2] belongs to the output rows, ln_s [N] to the columns;
-     * ln_side 2: ln_stats [batch][N][2] belongs to the output columns, ln_s [M] to the rows (the transposed V^T projection). */
+     * ln_side 1: ln_stats [batch][M][2] belongs to the output rows, ln_s [N] to the columns.  (ABI <= 9 had a column-side form 2
+     * for a transposed V^T projection; since ABI 10 V comes out of the fused QKV projection row-major - sdv_attention_bf16's
+     * v_rowmajor - and that launch form, its tile and its epilogue are gone.) */
     const float* ln_stats;
     const float* ln_s;
     float* stats_out;
@@ -113,20 +116,10 @@ typedef struct sdv_gemm_args {
      *   2  image epilogue of the VAE's conv_out 128 -> 3 (stable_diffusion_pipeline.py:432-438 + numpy_to_pil :450):
      *      v = clamp(v / 2 + 0.5, 0, 1) -> out_f32 [M][ldc] (optional) and out_u8 [M][ldc] = round-half-even(255 v) (optional)
      *   3  as 2 with v = clamp(v, 0, 1)            (RRDBNet conv_last of the Real-ESRGAN upsampler, upsampling.py:25-28)
-     * so that the two Cout <= 4 convolutions run on the matrix cores (N padded to one 32-column MFMA tile) instead of
-     * sdv_conv3x3_cout_small's one-wave-per-pixel reduction. */
+     * so that the Cout <= 4 convolutions run on the matrix cores (N padded to one 32-column MFMA tile). */
     int32_t out_mode;
     float* out_f32;
     uint8_t* out_u8;
-    /* conv modes, K-loop order of the 8-wave double-buffered tiles: 0 = tap-major (for each of the 9 taps: all channel slabs),
-     * 1 = channel-major (for each 64-channel slab: all taps).  Same products, a different summation order; channel-major
-     * re-reads a pixel's 128 bytes nine slabs in a row, so the 32 workgroups of an XCD keep their shifted windows inside the
-     * 4 MiB L2 instead of re-fetching every tap from the fabric (profiles/round3_*).  -1 = the library's default. */
-    int32_t k_order;
-    /* filled in by sdv_gemm_bf16: tile order of the persistent 8-wave workgroups.  0 = workgroup b takes tiles b, b + grid, ...
-     * of the XCD-aware raster; S > 0 = PANEL WALK: a workgroup takes whole M panels and walks tiles_n / S N tiles of each back
-     * to back (S workgroups share a panel), see sdv_gemm_set_walk.  Same tiles, same results - only the order changes. */
-    int32_t walk;
     /* GroupNorm statistics out of the producing epilogue (ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out: the
      * reference's nn.GroupNorm reads the tensor once for the statistics and once to normalise it; here the first read is gone).
      * gn_out != NULL: fp32 [batch * M / 32][2][gn_ld] - for every block of 32 output rows and every output column the (sum, sumsq)
@@ -148,13 +141,6 @@ int sdv_gemm_set_persistent(int on);
  * 32-tile problem WALKS tiles, so the tile-walk path (next tile's first K slab behind the epilogue) can be put under the
  * oracle-based parity gates at sizes the CPU oracle finishes in seconds.  Returns the previous setting. */
 int sdv_gemm_set_grid_limit(int n);
-/* Tile order of the persistent workgroups (sdv_gemm_args.walk): 0 = strided raster (workgroup b: tiles b, b + grid, ...);
- * S = 1 / 2 / 4: panel walk with S workgroups per M panel.  The walk is used only where it leaves every workgroup the same
- * number of tiles (M panels divisible over the panel slots), otherwise the launch falls back to the strided order.
- * Results are bit-identical either way.  Returns the previous setting.  EXPERIMENT (measured +-1.5 %, profiles/
- * round4_panel_walk_ab.txt): the kernels are built without it unless sdv_gemm.hip is compiled with -DSDV_PANEL_WALK=1 - the setter
- * then only records the value. */
-int sdv_gemm_set_walk(int s);
 /* partial (sum, sumsq) [rows][slots][2] -> (mean, rstd) [rows][2] over C channels */
 int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, int32_t C, float eps, float* out, void* stream);
 
@@ -163,8 +149,11 @@ int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, in
  * Replaces CrossAttention.forward inside the UNet (self: Lk = Lq; cross: Lk = 77).
  *   Q  [B][Lq][ldq]   head h at columns [h*dh, (h+1)*dh)
  *   K  [B][Lk][ldk]   same head layout
- *   Vt [B][H*dh][ldv] V TRANSPOSED (row = channel, column = key), ldv >= roundup(Lk,64), the
- *                     columns >= Lk must be finite (zero-filled)
+ *   Vt v_rowmajor == 0: [B][H*dh][ldv] V TRANSPOSED (row = channel, column = key), ldv >= roundup(Lk,64), the columns >= Lk
+ *                       must be finite (zero-filled) - the text context's V^T, projected once per walk;
+ *      v_rowmajor != 0: [B][Lk][ldv] V as the projection wrote it (same head layout as K, ldv = its row stride: the V columns of
+ *                       a fused [Q | K | V] projection - attn1.to_q / to_k / to_v of BasicTransformerBlock in ONE GEMM); the kernel
+ *                       transposes in the LDS read (ds_read_b64_tr_b16), so the UNet's self-attention has no V^T launch
  *   O  [B][Lq][ldo]
  * dh in {40, 64, 80, 160}.  causal != 0 masks key > query (CLIPTextModel's causal mask, reached from
  * text_encoder(ids)[0], stable_diffusion_pipeline.py:819; needs Lq == Lk).
@@ -176,7 +165,7 @@ int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, in
 int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O,
                        int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dh,
                        int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, int32_t causal,
-                       int32_t q_prescaled, void* stream);
+                       int32_t q_prescaled, int32_t v_rowmajor, void* stream);
 
 /* row softmax in place over bf16 rows (1 head x 512 channels; kept for callers that hold bf16 scores) */
 int sdv_softmax_rows_bf16(sdv_bf16* S, int64_t rows, int32_t cols, int32_t ld, void* stream);
@@ -223,13 +212,8 @@ int sdv_layernorm_bf16(const sdv_bf16* X, const float* gamma, const float* beta,
 /* ------------------------------------------------------------------------------------------
  * Small-channel direct convolutions (no MFMA: K or N too small for a tile).
  *   conv3x3_cin_small : Cin <= 8  (UNet conv_in 4->320, VAE decoder.conv_in 4->512), bf16 NHWC out
- *   conv3x3_cout_small: Cout <= 4 (UNet conv_out 320->4 -> fp32 eps; VAE conv_out 128->3 -> image)
- *     out_mode 0: fp32 NHWC out_f32 = conv + bias
- *     out_mode 1: image epilogue of stable_diffusion_pipeline.py:435-438 + numpy_to_pil (:450):
- *                 img = clamp(v/2+0.5, 0, 1) -> out_f32 (optional, fp32 NHWC) and
- *                 out_u8 = rint(img*255) (round-half-even) uint8 NHWC
- *     out_mode 2: as 1 with img = clamp(v, 0, 1): RealESRGANer.enhance post-processing (clamp_(0,1), (x*255).round()),
- *                 reached from upsampling.py:46
+ *   (the Cout <= 4 output convolutions - UNet conv_out 320->4, VAE conv_out 128->3, RRDBNet conv_last - run on the matrix cores:
+ *    sdv_gemm_args.out_mode; the one-wave-per-pixel sdv_conv3x3_cout_small of ABI <= 9 is gone)
  * ------------------------------------------------------------------------------------------ */
 int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Cin]*/, const float* bias,
                           sdv_bf16* Y, int32_t nimg, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
@@ -237,9 +221,6 @@ int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Ci
 /* im2col of a 4-channel NHWC image for a 3x3 pad-1 conv: Y[pixel][64] = [9 taps x 4 channels | 28 zeros]; the conv is
  * then sdv_gemm_bf16 with K = 64 against weights zero-padded the same way (UNet conv_in, VAE decoder.conv_in). */
 int sdv_im2col3x3_c4(const sdv_bf16* X, sdv_bf16* Y, int32_t nimg, int32_t H, int32_t Wd, int32_t circular, void* stream);
-int sdv_conv3x3_cout_small(const sdv_bf16* X, const sdv_bf16* W /*[Cout][3][3][Cin]*/, const float* bias,
-                           float* out_f32, uint8_t* out_u8, int32_t nimg, int32_t H, int32_t Wd,
-                           int32_t Cin, int32_t Cout, int32_t out_mode, int32_t circular, void* stream);
 
 /* z = Wpq * (x * in_scale) + b per pixel, fp32 NHWC latents -> bf16 NHWC (1/0.18215 scaling of
  * stable_diffusion_pipeline.py:432 fused with AutoencoderKL.post_quant_conv) */

@@ -8,9 +8,14 @@
 //   S^T[key][q] = K . Q^T      v_mfma_f32_32x32x16_bf16, A = K rows (LDS), B = Q rows (registers)
 //       -> lane l owns query q = l & 31 and 16 keys per 32-key subtile in its accumulator registers;
 //          the row max / row sum are register reductions plus ONE exchange with lane l^32.
-//   O^T[d][q]  = V^T . P^T     A = V^T rows (LDS, V is supplied transposed), B = P^T straight from the
-//       softmax registers (no cross-lane movement: the PV contraction may visit keys in any order as
-//       long as A and B agree, so the V^T tile is written to LDS in the MFMA C-layout key order).
+//   O^T[d][q]  = V^T . P^T     A = V^T rows, B = P^T straight from the softmax registers (no cross-lane movement: the
+//       PV contraction may visit keys in any order as long as A and B agree).  Two forms of the A operand:
+//         * V supplied TRANSPOSED ([head dim][keys], the text context's V^T, made once per walk): the tile is written to
+//           LDS in the MFMA C-layout key order and one ds_read_b128 yields a lane's 8 keys;
+//         * V supplied ROW-MAJOR (VRM: [keys][head dim] - the V columns of the fused QKV projection, so the UNet's
+//           self-attention needs no transposed V^T projection launch): the tile is staged exactly like K and the
+//           transpose happens in the LDS read - ds_read_b64_tr_b16 hands lane (d, 4-key group) the four keys of ITS
+//           d from four different rows (two reads per 8-key fragment).
 //   -> the running rescale O *= exp2(m_old - m_new) is also lane-local.
 // One workgroup = 4 waves x 32 queries = 128 queries of one head; K / V^T tiles of 64 keys are
 // register-staged (global -> VGPR issued before the MFMA phase, VGPR -> LDS after the barrier).
@@ -25,7 +30,7 @@ constexpr f32x16_t kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 
 #endif
 constexpr float kDefer = 5.0f;  // log2 units: skip the O rescale while the running max moves by < 2^5
 
-template <int DH>
+template <int DH, bool VRM = false>
 struct AttnCfg {
     static constexpr int DKS = (DH + 15) / 16;        // 16-wide k-steps of Q.K^T
     static constexpr int DKP = DKS * 16;              // padded head dim for Q.K^T
@@ -33,8 +38,15 @@ struct AttnCfg {
     static constexpr int DVP = DVT * 32;
     static constexpr int KROW = DKP * 2 + 16;         // LDS row stride of the K tile (odd # of 16-B slots)
     static constexpr int VROW = 64 * 2 + 16;          // LDS row stride of the V^T tile (64 keys)
+    // VRM: row stride of the row-major V tile (one row per key, DVP columns).  A transposing read covers 4 rows x 64 bytes
+    // per 32 lanes: conflict-free when the four rows start 64 bytes apart modulo the 256-byte bank row, i.e. the stride is
+    // an odd multiple of 64 bytes: 192 (dh 40 / 64: 128 bytes of columns), 192 (dh 80: 192), 320 (dh 160: 320)
+    static constexpr int VRS = (DVP * 2) % 128 == 64 ? DVP * 2 : DVP * 2 + 64;
     static constexpr int K_BYTES = 64 * KROW;
-    static constexpr int V_BYTES = DVP * VROW;
+    static constexpr int V_BYTES = VRM ? 64 * VRS : DVP * VROW;
+    // one K / V tile pair, or the four waves' Q / O slabs (32 rows x (DH * 2 + 16) bytes each) that alias the same region before
+    // the first and after the last tile - whichever is larger (dh 160 with a row-major V: the slabs)
+    static constexpr int LDS_BYTES = K_BYTES + V_BYTES > 4 * 32 * (DH * 2 + 16) ? K_BYTES + V_BYTES : 4 * 32 * (DH * 2 + 16);
     static constexpr int CPR = DH / 8;                // 16-B chunks per K row
     static constexpr int KCH = 64 * CPR;              // chunks per K tile
     static constexpr int VCH = DH * 8;                // chunks per V^T tile
@@ -51,8 +63,8 @@ struct AttnCfg {
 #define SDV_ATTN_RES_BLOCKS 8
 #endif
 constexpr int kResBlocks = SDV_ATTN_RES_BLOCKS;
-template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF, bool PP = false, int NW = 4, bool RES = false>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
+template <int DH, int QT, bool PRIO, bool LEAN, bool DBUF, bool PP = false, int NW = 4, bool RES = false, bool VRM = false>
+__global__ __launch_bounds__(NW * 64, (DH == 64 && VRM && !RES) ? 4 : 1) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ Kp,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                                                         float scale_log2e, int flags, int BH) {
@@ -60,11 +72,12 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     // QT = 32-query tiles per wave: the K / V^T fragments read from LDS are reused for QT MFMAs each.
     // NW = waves per workgroup: one staged K / V^T tile serves NW * QT * 32 queries (staging a tile costs ~17 % of the
     //      4-wave kernel's time in VMEM / LDS-write issue, tools/ubench/build_whatif.py variants 4-6).
-    using Cfg = AttnCfg<DH>;
+    using Cfg = AttnCfg<DH, VRM>;
+    static_assert(!(VRM && RES), "the resident (text cross-attention) form takes the walk's precomputed V^T");
     constexpr int NT = NW * 64;
     constexpr int KPT = (Cfg::KCH + NT - 1) / NT, VPT = (Cfg::VCH + NT - 1) / NT;
     static_assert(Cfg::KCH % 64 == 0 && Cfg::VCH % 64 == 0, "staging predicates must be wave-uniform");
-    constexpr int DKS = Cfg::DKS, DVT = Cfg::DVT, KROW = Cfg::KROW, VROW = Cfg::VROW;
+    constexpr int DKS = Cfg::DKS, DVT = Cfg::DVT, KROW = Cfg::KROW, VROW = Cfg::VROW, VRS = Cfg::VRS;
     // LEAN softmax - the dh = 40 / 80 kernels are VALU-issue-bound, not MFMA-bound (~150 VALU per 14 MFMAs at dh = 40):
     //  * Q is pre-multiplied by scale*log2(e) when its fragments are loaded, so scores come out of the MFMA in log2 units;
     //  * ONES (dh % 32 != 0, the V^T tile has padding rows): rows DH and DH+4 of the V^T tile hold 1.0, so the PV MFMA
@@ -120,7 +133,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     // ---- register staging of the next K / V^T tile --------------------------------------------
     u32x4_t kreg[KPT], vreg[VPT];
     const uint16_t* Kb = Kp + (long long)b * Lk * ldk + h * DH;
-    const uint16_t* Vb = Vt + ((long long)b * H + h) * DH * ldv;
+    // (VRM: `Vt` points at the V columns of the row-major [keys][ldv] buffer - a sample's rows follow each other as K's do)
+    const uint16_t* Vb = VRM ? Vt + (long long)b * Lk * ldv + h * DH : Vt + ((long long)b * H + h) * DH * ldv;
     // (chunk indices are clamped instead of predicated: surplus threads re-load / re-store the last
     //  chunk with identical data, which keeps the staging registers free of divergent control flow)
     // Buffer loads: the per-lane byte offsets are tile-invariant (computed once, here) and the tile position travels in
@@ -129,7 +143,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     // num_records and read as zero.
     const __amdgpu_buffer_rsrc_t rs_k =
         __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(Lk - 1) * ldk + DH) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((long long)DH * ldv * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Vb, 0, VRM ? (int)(((long long)(Lk - 1) * ldv + DH) * 2) : (int)((long long)DH * ldv * 2), 0x00020000);
     int kvo[KPT], vvo[VPT];
     // chunk c of a tile belongs to thread c % NT; KCH and VCH are multiples of 64, so "c < KCH" is the same for all
     // lanes of a wave: surplus WAVES skip their loads / stores altogether (no divergence, no redundant traffic)
@@ -142,19 +157,31 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int c = tid + i * NT;
-        const int row = c >> 3, cc = c & 7;
-        vvo[i] = (row * ldv + cc * 8) * 2;
+        if constexpr (VRM) {
+            const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;   // (key row, 16-byte piece of its DH columns) - as K
+            vvo[i] = (row * ldv + cc * 8) * 2;
+        } else {
+            const int row = c >> 3, cc = c & 7;
+            vvo[i] = (row * ldv + cc * 8) * 2;
+        }
     }
     auto load_tile = [&](int kv0) {
-        const int ks_off = kv0 * ldk * 2, vs_off = kv0 * 2;
+        const int ks_off = kv0 * ldk * 2, vs_off = VRM ? kv0 * ldv * 2 : kv0 * 2;
 #pragma unroll
         for (int i = 0; i < KPT; ++i)
             if (wave * 64 + i * NT < Cfg::KCH)
                 kreg[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_k, kvo[i], ks_off, 0));
+        // VRM, ragged last tile: the rows past this sample's last key belong to the NEXT sample (or lie past the tensor) and the
+        // scalar tile offset is not part of the range check - their pieces get a lane offset beyond num_records and read as zeros
+        // (P is 0 for those keys, but 0 x an Inf / NaN bit pattern would not be).  Wave-uniform branch, last tile only.
+        const bool ragged = VRM && kv0 + 64 > Lk;
 #pragma unroll
         for (int i = 0; i < VPT; ++i)
-            if (wave * 64 + i * NT < Cfg::VCH)
-                vreg[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vvo[i], vs_off, 0));
+            if (wave * 64 + i * NT < Cfg::VCH) {
+                int off = vvo[i];
+                if (ragged) off = kv0 + (tid + i * NT) / Cfg::CPR < Lk ? off : (int)0x80000000;
+                vreg[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_v, off, vs_off, 0));
+            }
     };
     auto store_tile = [&](int boff) {
 #pragma unroll
@@ -169,6 +196,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int c = tid + i * NT;
+            if constexpr (VRM) {     // row-major V: the rows as they come, one 16-byte piece per chunk (the read transposes)
+                const int row = c / Cfg::CPR, cc = c - row * Cfg::CPR;
+                if (wave * 64 + i * NT < Cfg::VCH) *(u32x4_t*)(ldsV + boff + row * VRS + cc * 16) = vreg[i];
+                continue;
+            }
             const int row = c >> 3, cc = c & 7;  // cc: 8-key chunk; block = cc>>1, half = cc&1
             if (wave * 64 + i * NT < Cfg::VCH) {
                 char* dst = ldsV + boff + row * VROW + (cc >> 1) * 32 + (cc & 1) * 8;
@@ -184,6 +216,9 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         if constexpr (ONES) {
             __syncthreads();
             for (int bf = 0; bf < NBUF; ++bf) {
+                if constexpr (VRM) {   // the same two rows of V^T are COLUMNS DH and DH + 4 of every key row here
+                    if (tid < 128) *(uint16_t*)(ldsV + bf * KV_BYTES + (tid >> 1) * VRS + (DH + 4 * (tid & 1)) * 2) = 0x3F80;
+                } else
                 if (tid < 16)   // rows DH (lanes 0-31 hold it in acc register ONES_R) and DH + 4 (lanes 32-63), 64 keys each
                     *(uint4*)(ldsV + bf * KV_BYTES + (DH + 4 * (tid >> 3)) * VROW + (tid & 7) * 16) =
                         make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
@@ -192,6 +227,24 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
             }
         }
 
+    };
+    // A operand of one PV MFMA: d-tile dt (32 rows of O^T), key group ju = (32-key subtile j, register half u) - this lane's 8
+    // keys are j*32 + 16u + 4 lhi + {0..3} and the same + 8 (the MFMA C layout of its P registers).
+    // VRM: lane (g = lane >> 4, i = lane & 15) of a transposing read addresses 4 columns [16 (g & 1) + 4 (i & 3), +4) of key row
+    // 4 lhi + (i >> 2) of the block and RECEIVES, for its own column d = 16 (g & 1) + i, the four keys of the block's rows.
+    const int vtr_lane = (4 * lhi + ((lane & 15) >> 2)) * VRS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto vfrag_at = [&](int boff, int dt, int ju) __attribute__((always_inline)) -> bf16x8_t {
+        if constexpr (VRM) {
+            typedef short __attribute__((ext_vector_type(4))) s16x4_t;
+            typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
+            const char* a = ldsV + boff + vtr_lane + ((ju >> 1) * 32 + (ju & 1) * 16) * VRS + dt * 64;
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a + 8 * VRS));
+            typedef short __attribute__((ext_vector_type(8))) s16x8_t;
+            return __builtin_bit_cast(bf16x8_t, s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+        } else {
+            return *(const bf16x8_t*)(ldsV + boff + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
+        }
     };
     const int ntiles = (Lk + 63) / 64;
     if constexpr (RES) {
@@ -232,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     constexpr int QROW = DH * 2 + 16;                 // slab row stride (bytes)
     constexpr int QSLAB = 32 * QROW;                  // one 32-query tile
     constexpr int QCH = 32 * Cfg::CPR;                // 16-byte pieces of a 32-query tile
-    static_assert(RES || NW * QSLAB <= NBUF * KV_BYTES, "the Q / O slabs alias the K / V^T buffers");
+    static_assert(RES || NW * QSLAB <= (NBUF == 1 ? Cfg::LDS_BYTES : NBUF * KV_BYTES), "the Q / O slabs alias the K / V^T buffers");
     // (dh = 64 keeps the direct accesses: the slab code cost it 6 VGPRs - 124 -> 130 - and with them the fourth wave per SIMD;
     //  -DSDV_ATTN_SLAB64=1 builds it the other way for A/B)
     constexpr bool SLAB_IO = DH != 64 || SDV_ATTN_SLAB64 || RES;
@@ -396,9 +449,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
 #pragma unroll
                     for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
             };
-            auto vfrag = [&](int dt, int ju) {
-                return *(const bf16x8_t*)(ldsV + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
-            };
+            auto vfrag = [&](int dt, int ju) __attribute__((always_inline)) { return vfrag_at(0, dt, ju); };
             auto exp_quarter = [&](const f32x16_t& a, int u) {                  // 8 scores -> one B fragment
                 u32x4_t pr;
 #pragma unroll
@@ -552,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
             for (int ju = 0; ju < 4; ++ju) {
-                const bf16x8_t vf = *(const bf16x8_t*)(ldsV + boff + (dt * 32 + l31) * VROW + ju * 32 + lhi * 16);
+                const bf16x8_t vf = vfrag_at(boff, dt, ju);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt][ju], o[qt][dt], 0, 0, 0);
@@ -613,25 +664,26 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     }   // query blocks
 }
 
-template <int DH, int QT>
+template <int DH, int QT, bool VRM>
 int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
-    using Cfg = AttnCfg<DH>;
+    using Cfg = AttnCfg<DH, VRM>;
     const int nqb = (Lq + 128 * QT - 1) / (128 * QT);
-    const bool qmajor = !causal && Lk <= 128;              // (see the kernel: query-major order for the text cross-attention)
+    // (see the kernel: query-major order + resident key tiles for the text cross-attention, whose V^T is made once per walk)
+    const bool qmajor = !VRM && !causal && Lk <= 128;
     dim3 grid(qmajor ? (unsigned)(((B * nqb + 7) / 8) * 8 * H) : (unsigned)(nqb * (((B * H + 7) / 8) * 8)));   // 1-D over (head group, query block, XCD slot)
     const int flags = (causal ? 1 : 0) | (qmajor ? 2 : 0);
     // Variants measured and not shipped (the template flags remain so that a tools build can instantiate them): one barrier per
     // tile with two K / V^T buffers (DBUF) -4 % at dh = 40 (8 more VGPRs -> 3 waves / SIMD), +-0 at dh = 80; no s_setprio
     // around the MFMA blocks (PRIO = false) -1..3 %; 8 waves per workgroup (NW = 8, one staged tile serves 512 queries) +-0.
-    const int lds = Cfg::K_BYTES + Cfg::V_BYTES;
+    const int lds = Cfg::LDS_BYTES;
     constexpr bool lean = DH % 32 != 0;   // dh = 64 / 160 have no padding rows or columns to move softmax work into
     const float sl = scale * 1.4426950408889634f;   // (the caller passes 1 / log2(e) for a pre-scaled Q: sl == 1, the
                                                     //  kernels' own Q scaling then reproduces the bf16 values bit for bit)
 #define SDV_ATTN_LAUNCH(P, L, D) \
-    hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, ldv, ldo, sl, \
-                       flags, B * H)
-    if constexpr (QT == 1 && DH <= 80) {   // (dh 160: the resident form needs 276 registers - one wave per SIMD - and is not built)
+    hipLaunchKernelGGL((attention_kernel<DH, QT, P, L, D, false, 4, false, VRM>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq, ldk, \
+                       ldv, ldo, sl, flags, B * H)
+    if constexpr (QT == 1 && DH <= 80 && !VRM) {   // (dh 160: the resident form needs 276 registers - one wave per SIMD - and is not built)
     if (qmajor) {
         // text cross-attention: both key tiles resident, kResBlocks query blocks per workgroup, query-major order
         const int nwg = (nqb + kResBlocks - 1) / kResBlocks;
@@ -657,8 +709,8 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
         // software-pipelined two-query-tile kernel: dh = 40, full key tiles only, no mask (the 64^2 self-attention; the caller
         // checks).  Two tiles per wave WITHOUT the pipelined body measured -3 % .. +1 % and are not compiled.
         static_assert(DH == 40, "two query tiles per wave exist for dh = 40 only");
-        hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq, Lk, ldq,
-                           ldk, ldv, ldo, sl, flags, B * H);
+        hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true, 4, false, VRM>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq,
+                           Lk, ldq, ldk, ldv, ldo, sl, flags, B * H);
     } else {
         SDV_ATTN_LAUNCH(true, lean, false);
     }
@@ -667,16 +719,16 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
     return SDV_OK;
 }
 
-template <int DH>
+template <int DH, bool VRM>
 int launch_attention(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, int B, int H, int Lq, int Lk,
                      int ldq, int ldk, int ldv, int ldo, float scale, int causal, hipStream_t s) {
     // Two 32-query tiles per wave (halves the LDS fragment traffic and barriers per MFMA, 2 waves / SIMD) with the
     // software-pipelined body: +5.5 % on the 64^2 self-attention (dh = 40, full key tiles, no mask).
     if constexpr (DH == 40) {
         const bool pp_ok = !causal && Lk % 64 == 0;
-        if (pp_ok && Lq >= 1024) return launch_attention_q<DH, 2>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        if (pp_ok && Lq >= 1024) return launch_attention_q<DH, 2, VRM>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
     }
-    return launch_attention_q<DH, 1>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+    return launch_attention_q<DH, 1, VRM>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
 }
 
 // ---- in-place row softmax over bf16 (VAE mid-block attention scores) -------------------------
@@ -763,20 +815,33 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __re
 
 extern "C" int sdv_attention_bf16(const sdv_bf16* Q, const sdv_bf16* K, const sdv_bf16* Vt, sdv_bf16* O, int32_t B,
                                   int32_t H, int32_t Lq, int32_t Lk, int32_t dh, int32_t ldq, int32_t ldk, int32_t ldv,
-                                  int32_t ldo, float scale, int32_t causal, int32_t q_prescaled, void* stream) {
+                                  int32_t ldo, float scale, int32_t causal, int32_t q_prescaled, int32_t v_rowmajor, void* stream) {
     if (q_prescaled) scale = 0.6931471805599453f;   // * log2(e) == 1
     SDV_REQUIRE(Q && K && Vt && O, "sdv_attention_bf16: null pointer");
     SDV_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sdv_attention_bf16: bad shape");
     SDV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "sdv_attention_bf16: unaligned leading dims");
     SDV_REQUIRE(dh == 40 || dh == 64 || dh == 80 || dh == 160, "sdv_attention_bf16: unsupported head dim %d (40/64/80/160)", dh);
     SDV_REQUIRE(((((uintptr_t)Q) | ((uintptr_t)O)) & 15) == 0, "sdv_attention_bf16: Q / O must be 16-byte aligned");
-    SDV_REQUIRE(ldv >= ((Lk + 63) / 64) * 64, "sdv_attention_bf16: ldv=%d must cover roundup(Lk=%d, 64)", ldv, Lk);
     hipStream_t s = (hipStream_t)stream;
+    if (v_rowmajor) {
+        // V row-major [B*Lk][ldv] (the V columns of a fused QKV projection): ldv is the row stride, like ldk
+        SDV_REQUIRE(ldv >= H * dh && (((uintptr_t)Vt) & 15) == 0, "sdv_attention_bf16: row-major V needs ldv=%d >= H*dh and a 16-byte aligned pointer", ldv);
+        SDV_REQUIRE(((long long)(Lk - 1) * ldv + dh) * 2 < 0x7fffffffLL && ((long long)(Lk - 1) * ldk + dh) * 2 < 0x7fffffffLL,
+                    "sdv_attention_bf16: one sample's K / V rows must span less than 2 GiB");
+        switch (dh) {
+            case 40: return launch_attention<40, true>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+            case 64: return launch_attention<64, true>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+            case 80: return launch_attention<80, true>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+            case 160: return launch_attention<160, true>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+            default: SDV_REQUIRE(false, "sdv_attention_bf16: unsupported head dim %d (40/64/80/160)", dh);
+        }
+    }
+    SDV_REQUIRE(ldv >= ((Lk + 63) / 64) * 64, "sdv_attention_bf16: ldv=%d must cover roundup(Lk=%d, 64)", ldv, Lk);
     switch (dh) {
-        case 40: return launch_attention<40>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
-        case 64: return launch_attention<64>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
-        case 80: return launch_attention<80>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
-        case 160: return launch_attention<160>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        case 40: return launch_attention<40, false>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        case 64: return launch_attention<64, false>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        case 80: return launch_attention<80, false>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
+        case 160: return launch_attention<160, false>(Q, K, Vt, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, scale, causal, s);
         default: SDV_REQUIRE(false, "sdv_attention_bf16: unsupported head dim %d (40/64/80/160)", dh);
     }
     return SDV_OK;

@@ -53,7 +53,9 @@ SDV_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.
 // t = 1 / (1 + p' |x|) (the 1/sqrt 2, the 0.5 and log2 e folded into p', the polynomial and k), gelu(x) = max(x, 0) - |x| h:
 // 11 plain VALU + v_rcp + v_exp instead of 18 + 2 (no copysign, no 1 + erf, no separate scaling of the argument).
 SDV_DEVICE float gelu_erf_fast_f(float x) {
-    const float ax = fabsf(x);
+    // (|x| capped at a finite value: at x = +inf the last FMA would otherwise be fma(-inf, 0, inf) = NaN where gelu(+inf) = +inf -
+    //  an overflowed GEGLU gate has to saturate, not poison the residual stream; one v_min with the |.| source modifier)
+    const float ax = fminf(fabsf(x), 1e18f);
     const float t = __frcp_rn(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
     const float u = x * 0.84932180028801904272f;                  // sqrt(0.5 * log2(e))
     const float e = __builtin_amdgcn_exp2f(-(u * u));

@@ -17,7 +17,7 @@ void sdv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sdv_last_error(void) { return g_err; }
-extern "C" int sdv_abi_version(void) { return 9; }
+extern "C" int sdv_abi_version(void) { return 10; }
 
 namespace {
 
@@ -416,76 +416,6 @@ __global__ __launch_bounds__(kThreads) void conv3x3_cin_small_kernel(const uint1
     }
 }
 
-// ---- direct conv3x3, tiny Cout (<= 4): one wave per output pixel, lanes split the 9*Cin reduction ----
-template <int COUT>
-__global__ __launch_bounds__(kThreads) void conv3x3_cout_small_kernel(const uint16_t* __restrict__ X,
-                                                                      const uint16_t* __restrict__ Wt,
-                                                                      const float* __restrict__ bias,
-                                                                      float* __restrict__ out_f32,
-                                                                      uint8_t* __restrict__ out_u8, int nimg, int H,
-                                                                      int Wd, int Cin, int out_mode, int circular) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint16_t* wl = (uint16_t*)smem_raw;  // [COUT][9][Cin] bf16 copy
-    const int wn = COUT * 9 * Cin;
-    for (int i = threadIdx.x * 8; i < wn; i += kThreads * 8) *(uint4*)(wl + i) = *(const uint4*)(Wt + i);
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int cchunks = Cin >> 3;        // 16-B chunks per pixel
-    const int nwork = 9 * cchunks;       // (tap, chunk) pairs, split over lanes
-    const long long npix = (long long)nimg * H * Wd;
-    for (long long pix = (long long)blockIdx.x * 4 + wave; pix < npix; pix += (long long)gridDim.x * 4) {
-        const int img = (int)(pix / ((long long)H * Wd));
-        const int rem = (int)(pix - (long long)img * H * Wd);
-        const int y = rem / Wd, x = rem - y * Wd;
-        float acc[COUT];
-#pragma unroll
-        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-        // 8 predicated slots per sweep so that all of a lane's 16-byte loads are in flight together
-        for (int wbase = 0; wbase < nwork; wbase += 512) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int wk = wbase + lane + it * 64;
-                if (wk >= nwork) continue;
-                const int tap = wk / cchunks, ch = wk - tap * cchunks;
-                int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-                if (circular) {
-                    iy = (iy + H) % H;
-                    ix = (ix + Wd) % Wd;
-                } else if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) {
-                    continue;
-                }
-                const bf16x8_raw xr = *(const bf16x8_raw*)(X + (((long long)img * H + iy) * Wd + ix) * Cin + ch * 8);
-                float xf[8];
-                unpack8(xr, xf);
-#pragma unroll
-                for (int o = 0; o < COUT; ++o) {
-                    const bf16x8_raw wr = *(const bf16x8_raw*)(wl + (o * 9 + tap) * Cin + ch * 8);
-                    float wf[8];
-                    unpack8(wr, wf);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[o] += xf[e] * wf[e];
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < COUT; ++o) acc[o] = wave_sum(acc[o]);
-        if (lane == 0) {
-#pragma unroll
-            for (int o = 0; o < COUT; ++o) {
-                float v = acc[o] + (bias ? bias[o] : 0.f);
-                if (out_mode == 0) {
-                    out_f32[pix * COUT + o] = v;
-                } else {
-                    v = out_mode == 1 ? fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f) : fminf(fmaxf(v, 0.f), 1.f);
-                    if (out_f32) out_f32[pix * COUT + o] = v;
-                    if (out_u8) out_u8[pix * COUT + o] = (uint8_t)rintf(v * 255.0f);
-                }
-            }
-        }
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -675,29 +605,3 @@ extern "C" int sdv_conv3x3_cin_small(const sdv_bf16* X, const sdv_bf16* W, const
     return SDV_OK;
 }
 
-extern "C" int sdv_conv3x3_cout_small(const sdv_bf16* X, const sdv_bf16* W, const float* bias, float* out_f32,
-                                      uint8_t* out_u8, int32_t nimg, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
-                                      int32_t out_mode, int32_t circular, void* stream) {
-    SDV_REQUIRE(X && W, "sdv_conv3x3_cout_small: null pointer");
-    SDV_REQUIRE(Cout >= 1 && Cout <= 4, "sdv_conv3x3_cout_small: Cout must be 1..4 (got %d)", Cout);
-    SDV_REQUIRE(Cin % 8 == 0 && Cin > 0, "sdv_conv3x3_cout_small: Cin must be a multiple of 8");
-    SDV_REQUIRE(out_mode >= 0 && out_mode <= 2, "sdv_conv3x3_cout_small: bad out_mode %d", out_mode);
-    SDV_REQUIRE(out_mode == 0 ? out_f32 != nullptr : (out_f32 || out_u8), "sdv_conv3x3_cout_small: no output buffer");
-    const size_t lds = (size_t)Cout * 9 * Cin * 2;
-    SDV_REQUIRE(lds <= 64 * 1024, "sdv_conv3x3_cout_small: weights do not fit LDS");
-    const long long npix = (long long)nimg * H * Wd;
-    const unsigned grid = grid_for(npix, 4, 8192);
-    hipStream_t s = (hipStream_t)stream;
-#define SDV_LAUNCH_CO(CO)                                                                                           \
-    hipLaunchKernelGGL(conv3x3_cout_small_kernel<CO>, dim3(grid), dim3(kThreads), lds, s, X, W, bias, out_f32, out_u8, \
-                       nimg, H, Wd, Cin, out_mode, circular)
-    switch (Cout) {
-        case 1: SDV_LAUNCH_CO(1); break;
-        case 2: SDV_LAUNCH_CO(2); break;
-        case 3: SDV_LAUNCH_CO(3); break;
-        default: SDV_LAUNCH_CO(4); break;
-    }
-#undef SDV_LAUNCH_CO
-    SDV_CHECK_LAUNCH("sdv_conv3x3_cout_small");
-    return SDV_OK;
-}

@@ -26,45 +26,23 @@
 
 #include "sdv_common.h"
 
-// W fragments in flight ahead of the MFMAs in the bf16 K loop of the big (kPipeFrags) tiles; 0 = the round-2 order (two whole
-// fragment sets, compiler-scheduled) - kept for A/B builds (tools/ubench/build_variant.py ah0 -DSDV_BF16_ROT_AH=0).
-#ifndef SDV_BF16_ROT_AH
-#define SDV_BF16_ROT_AH 2
-#endif
-
-// GEGLU epilogue: 1 = the rearranged exact-erf GELU (sdv_common.h gelu_erf_fast_f, 11 + 2 VALU), 0 = the round-1 form (18 + 2) -
-// kept for A/B builds (tools/ubench/build_variant.py gelu0 -DSDV_GELU_FAST=0).
-#ifndef SDV_GELU_FAST
-#define SDV_GELU_FAST 1
-#endif
-
-// +residual epilogue of the tiles with two staging slabs per wave: 1 = 64-column fp32 passes through ONE 8.5 KB slab (32 rows x
-// (256 + 16) bytes) - every residual load and every store then covers 8 rows x 128 B, whole cache lines; 0 = 32-column fp32 passes
-// through two 4.5 KB slabs (16 rows x 64 B per instruction) - kept for A/B builds (tools/ubench/build_variant.py res32 -DSDV_RES_PASS64=0).
-// Panel walk of the persistent tiles (sdv_hip.h "walk").  Measured +-1.5 % per shape and nothing on the forward
-// (profiles/round4_panel_walk_ab.txt) - and its tile-index arithmetic, merely compiled in, cost the 256 x 320 conv 20 B of scratch
-// and 1-2 % (profiles/round4_round3_vs_round4_gemm.txt), so it is compiled OUT by default: sdv_gemm_set_walk() then has no effect.
-// tools/walk_ab.py runs against a -DSDV_PANEL_WALK=1 build (tools/ubench/build_variant.py walk -DSDV_PANEL_WALK=1).
-#ifndef SDV_PANEL_WALK
-#define SDV_PANEL_WALK 0
-#endif
-#ifndef SDV_RES_PASS64
-#define SDV_RES_PASS64 1
-#endif
+// (The A/B knobs of rounds 2-4 - W fragments ahead, GELU form, 32-column residual passes, panel walk, channel-major K order, the
+//  LDS-ring tiles 12 / 13, the transposed 320 x 256 tile 14 with the column-side LayerNorm fold - lived here as #if branches and
+//  extra template instances.  Their measurements are under profiles/; the source that can rebuild any of them is the round-4
+//  tree (git 2b6591d) through tools/ubench/build_variant.py.  This file keeps what the cost model can pick.)
+constexpr int kRotAhead = 2;   // W fragments in flight ahead of the MFMAs in the bf16 K loop of the big tiles (profiles/round3_rot_w_fragments_ab.txt)
 
 namespace {
 
-SDV_DEVICE float geglu_gate_f(float x) { return SDV_GELU_FAST ? gelu_erf_fast_f(x) : gelu_erf_f(x); }
+SDV_DEVICE float geglu_gate_f(float x) { return gelu_erf_fast_f(x); }   // (rearranged exact-erf GELU: profiles/round4_geglu_gelu_ab.txt)
 
 // waves per SIMD the register allocator must leave room for: the 32-wide-K tiles are meant to run two workgroups
 // per CU (16 waves -> 4 per SIMD -> <= 128 VGPRs)
-// NST = K-tile buffers in LDS.  2: double buffer, one `vmcnt(0)` + barrier per tile (the small / 64-wide-K tiles).
-// >2: a ring of NST 32-wide K tiles, NST-1 of them in flight by LDS-DMA ACROSS the barriers (counted `s_waitcnt vmcnt(N)`,
-// raw `s_barrier`): three tiles of loads per CU in flight keep HBM busy for the K <= 640 projections, the barrier sits in
-// the MIDDLE of a tile's MFMAs (fragments of the second k-step are already in registers), and the DMA issue and every
-// fragment read are slotted behind MFMAs instead of in front of them.
+// NST = K-slab buffers in LDS: always 2 (double buffer, one `vmcnt(0)` + barrier per K slab; the 4-slot ring form of rounds 2-3
+// measured 2-14 % slower on every transformer shape - profiles/round3_ring_ab_nimg256.txt - and is gone; the parameter stays so that
+// kernel names in earlier profiles still read the same).
 // FEAT compiles ONE of the LayerNorm-fold features into the epilogue (dense GEMMs of the transformer blocks only - each costs
-// registers the 256-row tiles do not have to spare): 1 = ln_side 1 consumer, 2 = ln_side 2 consumer, 3 = stats_out producer,
+// registers the 256-row tiles do not have to spare): 1 = ln_side 1 consumer, 3 = stats_out producer,
 // 4 = gn_out producer (GroupNorm statistics of the stored tile; the 4-wave tiles carry that inside FEAT 0 - they have the registers).
 template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST = 2, int FEAT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * WM * WN / 4)) void igemm_kernel(const sdv_gemm_args p) {
@@ -93,7 +71,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     constexpr int NX = (GX + NWV - 1) / NWV, NW = (GW + NWV - 1) / NWV;
     constexpr int KSTEPS = BK / 16;
     static_assert(BM % RPI == 0 && BN % RPI == 0, "panels must be whole 1-KiB groups");
-    static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(BK == 64 && NST == 2, "64-wide K slabs, double buffered");
+    static_assert(FEAT != 2, "(FEAT 2 was the column-side LayerNorm fold of the transposed V^T projections: gone with them)");
     static_assert(FEAT != 8 || (BK == 64 && NST == 2), "fp8 tiles: 64 elements (64 bytes) per K tile, double buffered");
     static_assert(!MX || (BK == 64 && NST == 2), "MX fp8 tiles: two 64-element images per K tile, double buffered");
 
@@ -112,15 +91,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     // tile's first MFMAs: with one workgroup per CU nothing else can cover those two latencies (they were 8-9 us of a 19 us
     // K = 320 tile, profiles/round2_gemm_overhead.txt), and the CUs stop moving through load / compute / store phases in
     // lockstep.  Every other tile runs this loop exactly once (grid = tiles).
-    constexpr bool RING = NST > 2;
-    constexpr bool PERSIST = NWV == 8 && (!RING || !CONV);   // (ring tiles walk only as dense GEMMs - the short-K shapes they exist for)
+    constexpr bool PERSIST = NWV == 8;
     // LDS: NST K-slab buffers of SLOT bytes, then the epilogue's column vectors (3 x BN floats) and row accumulators.  The
     // epilogue's staging slabs (SLAB bytes per wave) alias the K-slab buffers - in a persistent workgroup the ONE slot the
     // tile's last K slab was read from, the other slot already receives the next tile.
     constexpr int SLAB = 32 * 144;   // 32 rows x (128 + 16 pad) bytes
-    // (ring tiles: ONE staging slab per wave, in the ring slot the tile's last K slab was read from - the other NST-1 slots
-    //  already hold the next tile's first K slabs)
-    constexpr int STG = (RING ? 1 : 2) * NWV * SLAB;
+    constexpr int STG = 2 * NWV * SLAB;
     constexpr int SLOT = PERSIST ? (TILE_BYTES > STG ? TILE_BYTES : STG) : TILE_BYTES;
     // two slabs per wave (pass p+1 is parked while pass p is read back) wherever the K-slab buffers have the room
     constexpr bool DBL = (PERSIST ? SLOT : NST * SLOT) >= 2 * NWV * SLAB;
@@ -156,34 +132,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     unsigned wvo[NW];          // lane byte offsets of the W rows relative to rs_w
     unsigned xvo[NX];
     int tap = 0, srcsel = 0, seg_left = 0;
-    bool dead_stream = false;   // ring tiles, last tile of a workgroup: the pieces past the tile's last K slab read nothing
     int kx = 0;   // scalar byte offset inside the current X source
     int halves_left = 0;   // MX: 64-wide K images of the current tile not yet staged (0 -> the slab's second image is dead)
     int kwb = 0;  // scalar byte offset along the W rows (all taps and sources are contiguous in K)
 
-    // channel-major K order (sdv_hip.h k_order 1) - an EXPERIMENT kept selectable: it cuts the conv's fabric reads 3.2x and is
-    // 5-12 % slower (profiles/round3_conv_k_order.txt), so the default stays tap-major
-    const bool chan_major = CONV && p.k_order == 1 && p.mode != 0;
     auto setup_tile = [&](int vb) {
         int bm, bn, bz;
-        if (SDV_PANEL_WALK && PERSIST && p.walk > 0) {
-            // PANEL WALK (sdv_hip.h "walk"): a workgroup takes whole M panels and walks `tiles_n / S` N tiles of each back to back,
-            // so that from the second N tile on its X panel comes out of the L2 / Infinity Cache it has just been pulled through
-            // instead of HBM (the default order only shares a panel between CUs that miss on it at the same time).  XCD x owns a
-            // contiguous run of panels (neighbouring conv panels share their halo rows through that XCD's L2); inside it the
-            // G/8 workgroups form J = G/8/S panel slots of S workgroups, each workgroup one N range of the slot's panels.
-            const int G = (int)gridDim.x;
-            const int it = vb / G, b = vb - it * G;
-            const int S = p.walk, J = (G >> 3) / S, per = tiles_n / S;
-            const int xcd = b & 7, j = b >> 3;
-            const int slot = j / S, nsub = j - slot * S;
-            const int xq = tiles_m >> 3, xr = tiles_m & 7;
-            const int start = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
-            const int kp = it / per;
-            bm = start + slot + kp * J;
-            bn = nsub * per + (it - kp * per);
-            bz = 0;
-        } else {
+        {
         bz = vb / nblk;           // batch index (mode 4: the phase)
         const int lb = vb - bz * nblk;
         // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs; remap
@@ -262,7 +217,6 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         seg_left = 0;
         kx = 0;
         kwb = 0;
-        dead_stream = false;
         halves_left = (K / BK) * (CONV ? (p.mode == 4 ? 4 : 9) : 1);
     };
 
@@ -287,63 +241,21 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     vx = vx < 0 ? vx + ext_x : (vx >= ext_x ? vx - ext_x : vx);
                 }
                 const int iy = vy >> up_shift, ix = vx >> up_shift;
-                const bool ok = ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win) & (xr_[i] >= 0) & !dead_stream;
+                const bool ok = ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win) & (xr_[i] >= 0);
                 const int pix = xr_[i] + iy * p.Win + ix;
                 xvo[i] = ok ? (unsigned)(pix * ld2 + xlc[i]) : kOOB;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xvo[i] = (xr_[i] >= 0 && !dead_stream) ? (unsigned)(xr_[i] * ld2 + xlc[i]) : kOOB;
+            for (int i = 0; i < NX; ++i) xvo[i] = xr_[i] >= 0 ? (unsigned)(xr_[i] * ld2 + xlc[i]) : kOOB;
         }
         kx = 0;
         seg_left = (srcsel ? K - p.C1 : p.C1) / BK;
     };
 
-    // Channel-major K order (sdv_hip.h k_order 1, conv modes): for each 64-channel slab ALL taps, so that a pixel's 128 bytes are
-    // re-read nine slabs in a row (from L2) instead of once per tap pass with the whole window in between.  The per-lane tap
-    // offsets are recomputed every slab (new_segment's ~10 VALU per X piece, hidden under the slab's 40 MFMAs); W columns are
-    // [tap][source][channel], so the slab's W offset is tap * K + (source 2 ? C1 : 0) + channel.
-    const int ntaps_k = CONV ? (p.mode == 4 ? 4 : 9) : 1;
     // `issue` false: only the bookkeeping of a slab that is already in LDS (the prefetched first slab of a persistent tile)
     auto stage = [&](int buf, bool issue = true) {
         char* base = smem + buf * SLOT;
-        if constexpr (CONV) {
-            if (chan_major) {
-                if (issue) {
-                    const int x_soff = kx;
-                    {
-                        const int kx_keep = kx;
-                        new_segment();             // xvo for (tap, srcsel); it also resets kx / seg_left, which this order does not use
-                        kx = kx_keep;
-                    }
-                    const __amdgpu_buffer_rsrc_t rs_xc = srcsel ? rs_x2 : rs_x1;
-                    const int kw_off = (tap * K + (srcsel ? p.C1 : 0)) * ES + kx;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        const int g = wave + NWV * i;
-                        if (GX % NWV == 0 || g < GX)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xc, (__attribute__((address_space(3))) void*)(base + g * 1024), 16,
-                                                                     (int)xvo[i], x_soff, 0, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < NW; ++i) {
-                        const int g = wave + NWV * i;
-                        if (GW % NWV == 0 || g < GW)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024),
-                                                                     16, (int)wvo[i], kw_off, 0, 0);
-                    }
-                }
-                if (++tap == ntaps_k) {            // next channel slab (of this source, then of the second one)
-                    tap = 0;
-                    kx += ROWB;
-                    if (kx == (srcsel ? K - p.C1 : p.C1) * ES) {
-                        kx = 0;
-                        srcsel = (two_src && srcsel == 0) ? 1 : 0;
-                    }
-                }
-                return;
-            }
-        }
 #pragma unroll
         for (int hf = 0; hf < (MX ? 2 : 1); ++hf, base += HALF_BYTES) {
         // MX: an odd number of 64-wide K images leaves the last slab's SECOND image dead - every piece of it gets an offset
@@ -484,7 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             }
             return;
         }
-        if constexpr (SDV_BF16_ROT_AH > 0) {
+        {
             // Rotating W fragments (the MX order above, for the bf16 tiles): a step = ONE W fragment against the TM X fragments of
             // its k-step.  Live fragment registers: X of this k-step and - from AH steps before its first use - of the next one
             // (2 x TM x 4), one W fragment in use and AH in flight behind the TM MFMAs of each step ((AH + 1) x 4): 28 registers
@@ -492,35 +404,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             // k-steps of a slab and fallen back to read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per W fragment, the LDS latency of every
             // read exposed (ISA of round 3); here the issue order is pinned by the sched_barriers and every read has AH x TM MFMAs
             // (64 matrix-pipe cycles each pair) to land.  Same accumulation order per output tile: bit-identical results.
-            if constexpr (TM > TN) {
-                // the mirrored form for tiles that are taller than wide per wave (the 320 x 256 tile of the transposed V^T projections:
-                // TM 5, TN 2): the W fragments of a k-step stay, the X fragments rotate - same k order per output tile, same registers
-                constexpr int AH = SDV_BF16_ROT_AH, STEPS = KSTEPS * TM;
-                bf16x8_t wa[2][TN], xq[AH + 1];
-                auto xfrag = [&](int st) __attribute__((always_inline)) {
-                    return *(const bf16x8_t*)(base + (xrow0 + (st % TM) * 32) * ROWB + frag_off[st / TM]);
-                };
-#pragma unroll
-                for (int nt = 0; nt < TN; ++nt) wa[0][nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[0]);
-#pragma unroll
-                for (int a = 0; a < AH; ++a) xq[a] = xfrag(a);
-#pragma unroll
-                for (int st = 0; st < STEPS; ++st) {
-                    const int ks = st / TM, mt = st % TM;
-                    if (st + AH < STEPS) xq[(st + AH) % (AH + 1)] = xfrag(st + AH);
-                    if (mt == (TM - 1 - AH >= 0 ? TM - 1 - AH : 0) && ks + 1 < KSTEPS) {
-#pragma unroll
-                        for (int nt = 0; nt < TN; ++nt)
-                            wa[(ks + 1) & 1][nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[ks + 1]);
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < TN; ++nt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks & 1][nt], xq[st % (AH + 1)], acc[nt][mt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                return;
-            }
-            constexpr int AH = SDV_BF16_ROT_AH, STEPS = KSTEPS * TN;
+            constexpr int AH = kRotAhead, STEPS = KSTEPS * TN;
             bf16x8_t xa[2][TM], wq[AH + 1];
             auto wfrag = [&](int st) __attribute__((always_inline)) {
                 return *(const bf16x8_t*)(base + (wrow0 + (st % TN) * 32) * ROWB + frag_off[st / TN]);
@@ -545,30 +429,6 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             }
             return;
         }
-        bf16x8_t xf[2][TM], wf[2][TN];
-        auto load_frags = [&](int ks, bf16x8_t* xd, bf16x8_t* wd) {
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[ks]);
-#pragma unroll
-            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[ks]);
-        };
-        load_frags(0, xf[0], wf[0]);
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            if (ks + 1 < KSTEPS) load_frags(ks + 1, xf[(ks + 1) & 1], wf[(ks + 1) & 1]);
-#pragma unroll
-            for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < TM; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], xf[ks & 1][mt], acc[nt][mt], 0, 0, 0);
-            if (ks + 1 < KSTEPS) {
-#pragma unroll
-                for (int i = 0; i < TM + TN; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-                }
-            }
-        }
     };
 
     const int ntaps = CONV ? (p.mode == 4 ? 4 : 9) : 1;
@@ -579,177 +439,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     int slot0 = 0;
     bool landed = false;
     bool has_next = false;
-    int cb = 0;         // ring tiles: slot of the K slab being computed - the ring keeps turning across tiles
-    int cb_stage = 0;   //             slot the tile's LAST slab was read from = where its epilogue stages
     auto kloop = [&]() {
-    if constexpr (NST > 2) {
-        // ---- ring main loop ------------------------------------------------------------------------------
-        static_assert(KSTEPS == 2, "ring tiles are 32 wide in K");
-        constexpr int PER = NX + NW;   // LDS-DMA pieces EVERY wave issues per K tile (uniform, so the vmcnt counts are constants)
-        static_assert(GX % NWV == 0, "ring tiles: X panel pieces must divide evenly over the waves");
-        auto issue_pieces = [&](char* base) {
-            const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
-            // (the K positions are wave-uniform by construction; said explicitly, because once they travel around the persistent
-            //  tile loop the compiler's uniformity analysis gives up and wraps every piece in a waterfall loop - guide T20)
-            const int kx_s = __builtin_amdgcn_readfirstlane(kx), kwb_s = __builtin_amdgcn_readfirstlane(kwb);
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(base + (wave + NWV * i) * 1024),
-                                                         16, (int)xvo[i], kx_s, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                int g = wave + NWV * i;
-                unsigned off = wvo[i];
-                if (GW % NWV != 0 && i == NW - 1) {
-                    // surplus slot of the last round: repeat this wave's previous piece (same bytes to the same LDS address)
-                    const bool dup = g >= GW;
-                    g = dup ? g - NWV : g;
-                    off = dup ? wvo[i > 0 ? i - 1 : 0] : off;
-                }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (GX + g) * 1024), 16,
-                                                         (int)off, kwb_s, 0, 0);
-            }
-        };
-        auto advance = [&]() {   // K-position bookkeeping of the piece stream (kept out of the MFMA blocks: it branches)
-            kx += ROWB;
-            kwb += ROWB;
-            if (--seg_left == 0) {
-                if (two_src && srcsel == 0) {
-                    srcsel = 1;
-                } else {
-                    srcsel = 0;
-                    ++tap;
-                }
-            }
-        };
-        auto issue_all = [&](char* base) {
-            if (seg_left == 0) new_segment();
-            issue_pieces(base);
-            advance();
-        };
-        // Wait until at most `ahead` K tiles of this wave's pieces are still in flight (VMEM returns in order, so the oldest
-        // tile has landed) AND this wave's fragment reads have returned (lgkmcnt): after the barrier that follows, the ring
-        // slot those reads came from is handed back to the LDS-DMA.
-        auto wait_stages = [&](int ahead) {
-            if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * PER) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        };
-        bf16x8_t fax[TM], faw[TN], fbx[TM], fbw[TN];
-        auto read_frags = [&](const char* base, int ks, bf16x8_t* xd, bf16x8_t* wd) {
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) xd[mt] = *(const bf16x8_t*)(base + (xrow0 + mt * 32) * ROWB + frag_off[ks]);
-#pragma unroll
-            for (int nt = 0; nt < TN; ++nt) wd[nt] = *(const bf16x8_t*)(base + (wrow0 + nt * 32) * ROWB + frag_off[ks]);
-        };
-        auto mfmas = [&](const bf16x8_t* xs, const bf16x8_t* ws) {
-#pragma unroll
-            for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < TM; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[nt], xs[mt], acc[nt][mt], 0, 0, 0);
-        };
-        auto slot_at = [&](int sl) { return smem + sl * SLOT; };
-        // Prologue.  First tile of a workgroup: fill the ring, wait for K slab 0.  Later tiles of a PERSISTENT workgroup: the
-        // ring never stopped - K slabs 0 .. NST-2 of this tile were issued behind the last NST-1 slabs of the tile before (and
-        // waited for ahead of its epilogue, so nothing this tile reads early queues behind that epilogue's stores); only their
-        // bookkeeping is replayed here, and slab NST-1 goes into the slot the epilogue staged in as soon as every wave has read
-        // its staging slab back.  (The host launches ring tiles persistently only when a tile has >= NST K slabs.)
-        // (the stream of pieces NEVER thins out: where no K slab is left to fetch - the tail of a workgroup's last tile, tiles
-        //  with fewer than NST slabs - it carries "dead" pieces whose offsets lie outside the buffers: the range check answers
-        //  them with zeros without touching memory, they land in a slot nobody reads any more, and every counted wait in the loop
-        //  stays the same constant)
-        auto go_dead = [&]() {
-            dead_stream = true;
-            seg_left = 0;          // -> new_segment() at the next issue, which now writes out-of-range offsets
-#pragma unroll
-            for (int i = 0; i < NW; ++i) wvo[i] = kOOB;
-        };
-        if (!(PERSIST && landed)) {
-#pragma nounroll
-            for (int sl = 0; sl < NST; ++sl) {
-                if (sl == nkt) go_dead();
-                issue_all(slot_at(sl));
-            }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * PER) : "memory");
-            __builtin_amdgcn_s_barrier();
-        } else {
-            for (int sl = 0; sl + 1 < NST; ++sl) {
-                if (seg_left == 0) new_segment();
-                advance();
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue_all(slot_at(cb_stage));
-        }
-        read_frags(slot_at(cb), 0, fax, faw);
-        // One K tile: [k-step 0 MFMAs || fragment reads of k-step 1] -> counted wait + barrier (tile kt+1 is now visible to
-        // every wave and nobody reads tile kt from LDS any more) -> [k-step 1 MFMAs || fragment reads of tile kt+1 ||
-        // LDS-DMA of tile kt+NST into the slot tile kt just left].
-        auto body = [&](auto ISSUE, auto NEXT, int ahead) {
-            constexpr bool issue = decltype(ISSUE)::value, next = decltype(NEXT)::value;
-            const char* cur = slot_at(cb);
-            read_frags(cur, 1, fbx, fbw);
-            mfmas(fax, faw);
-#pragma unroll
-            for (int i = 0; i < TM + TN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-            }
-            if constexpr (next) {
-                __builtin_amdgcn_sched_barrier(0);   // all k-step-0 MFMAs are issued before the wait: they cover the last reads
-                wait_stages(ahead);
-                __builtin_amdgcn_s_barrier();
-                const int nb = cb + 1 == NST ? 0 : cb + 1;
-                if constexpr (issue)
-                    if (seg_left == 0) new_segment();
-                read_frags(slot_at(nb), 0, fax, faw);
-                if constexpr (issue) issue_pieces(slot_at(cb));
-                mfmas(fbx, fbw);
-#pragma unroll
-                // (the LDS-DMA pieces write LDS, so the compiler keeps them behind the fragment reads: reads go behind the
-                //  first TM+TN MFMAs, the pieces are spread over the MFMAs that remain)
-                for (int i = 0; i < TM * TN; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-                    if (i < TM + TN) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // 1 DS read
-                    } else if (issue) {
-                        constexpr int kGaps = TM * TN - (TM + TN) > 0 ? TM * TN - (TM + TN) : 1;
-                        const int j = i - (TM + TN);
-                        const int n = (PER * (j + 1)) / kGaps - (PER * j) / kGaps;
-#pragma unroll
-                        for (int q = 0; q < n; ++q) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // LDS-DMA pieces
-                    }
-                }
-                if constexpr (issue) advance();
-                cb = nb;
-            } else {
-                mfmas(fbx, fbw);
-            }
-        };
-        // ONE instance of the steady-state body, always issuing PER pieces (so every counted wait is the same constant): slabs
-        // kt + NST of this tile, then - persistent workgroups - slabs 0 .. NST-2 of the NEXT tile (the addressing is re-pointed
-        // between the two runs of the loop), or, for the last tile of a workgroup, pieces whose offsets lie outside the buffers
-        // (the range check answers them with zeros without touching memory; the slot they land in is dead).  The tile's last
-        // slab issues nothing: its slot is the epilogue's staging area.
-        {
-            int kt = 0;
-            const int kswitch = nkt > NST ? nkt - NST : 0;
-#pragma nounroll
-            for (int ph = 0; ph < 2; ++ph) {
-                const int kend = ph == 0 ? kswitch : nkt - 1;
-#pragma nounroll
-                for (; kt < kend; ++kt) body(std::true_type{}, std::true_type{}, NST - 2);
-                if (ph == 0) {
-                    if (PERSIST && has_next) setup_tile(vb + (int)gridDim.x);
-                    else if (!dead_stream) go_dead();
-                }
-            }
-        }
-        body(std::false_type{}, std::false_type{}, 0);
-        cb_stage = cb;
-        cb = cb + 1 == NST ? 0 : cb + 1;
-    } else {
+    {
     // ---- main loop: one barrier per K tile, tile t+1 in flight (LDS-DMA) while tile t computes ----
     // The barriers here are RAW (own LDS reads retired + s_barrier): __syncthreads() is lowered to s_waitcnt vmcnt(0) +
     // s_barrier, and in a persistent workgroup that would make the first slab of every tile wait for the PREVIOUS tile's
@@ -834,26 +525,20 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             //  read back as 16-byte pieces in another, and type-based alias analysis must not reorder the two)
             typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) slab_u4;
             typedef unsigned int __attribute__((ext_vector_type(2), may_alias)) slab_u2;
-            char* const stg_region = !PERSIST ? smem : (RING ? smem + cb_stage * SLOT : smem + ((slot0 + nkt - 1) & 1) * SLOT);
+            char* const stg_region = !PERSIST ? smem : smem + ((slot0 + nkt - 1) & 1) * SLOT;
             char* const slab0 = stg_region + wave * (DBL ? 2 : 1) * SLAB;
             // Per-column epilogue vectors of this tile's BN columns, staged in LDS ONCE per tile (their own region behind the
             // K-slab buffers): bias, the LayerNorm-fold row sums s (ln_side 1) or the per-column (mean, rstd) (ln_side 2).
             float* vbias = (float*)(smem + NST * SLOT);
-            float* vaux = vbias + BN;            // [BN] (ln_side 1) or [BN][2] (ln_side 2)
+            float* vaux = vbias + BN;            // [BN] (ln_side 1: the row sums s of the gamma-scaled weights)
             float* rowacc = vbias + 3 * BN + wave * 64;   // FEAT 3: (sum, sumsq) of this wave's 32 rows of the current m-tile
-            // FEAT 2 (column-side fold): the per-ROW operands - s of the row, the row's bias - of the tile's BM rows, staged with the
-            // column vectors and read back per pass: held in registers for all TM m-tiles they spilled 268 B per lane at TM = 5
-            float* rowvec = vbias + 3 * BN;               // [BM][2] (same bytes as rowacc: FEAT 3 and FEAT 2 never meet)
-            // (only where TM > 2 - the 320 x 256 tile: the tiles the cost model picks keep the row operands in registers and the
-            //  fold expression exactly as round 3 compiled them, see the note at the candidates list)
-            constexpr bool ROWV = FEAT == 2 && TM > 2;
             const int mfirst = m0 < p.M ? m0 : p.M - 1;
             const long long orow0 = out_row(mfirst);
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(C + orow0 * p.ldc), 0, kRecords, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_r =
                 __builtin_amdgcn_make_buffer_rsrc((void*)(R ? R + orow0 * p.ldr : C), 0, kRecords, 0x00020000);
             // per-ROW operands of this lane's TM accumulator rows, fetched before the barrier (their latency hides behind it):
-            // LayerNorm fold: ln_side 1 -> (mean, rstd) of the row, ln_side 2 -> s of the row; bias_mode 2: the row's bias
+            // LayerNorm fold (ln_side 1): (mean, rstd) of the row; bias_mode 2: the row's bias
             float ln_row[TM][2], bm_[TM];
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
@@ -861,68 +546,41 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 ln_row[mt][1] = 1.f;
                 const int mrow = m0 + wm * TM * 32 + mt * 32 + l31;
                 const bool ok = mrow < p.M;
-                bm_[mt] = (!ROWV && bias && p.bias_mode == 2 && ok) ? bias[mrow] : 0.f;
+                bm_[mt] = (bias && p.bias_mode == 2 && ok) ? bias[mrow] : 0.f;
                 if constexpr (FEAT == 1) {
                     if (ok) {
                         const float2 st = *(const float2*)(p.ln_stats + 2 * (bz * p.M + mrow));
                         ln_row[mt][0] = st.x;
                         ln_row[mt][1] = st.y;
                     }
-                } else if constexpr (FEAT == 2 && !ROWV) {
-                    if (ok) ln_row[mt][0] = p.ln_s[mrow];
                 }
             }
             {
                 // (one element per thread - BN <= 512 - so that the global loads are all issued BEFORE the wait below and
                 //  their latency overlaps the tail of the prefetch instead of following it)
                 constexpr int NV = (BN + NWV * 64 - 1) / (NWV * 64);   // elements per thread (1; 2 for the 4-wave 320-column tile)
-                constexpr int lnsd = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
+                constexpr int lnsd = FEAT == 1 ? 1 : 0;
                 const bool col_bias = bias && p.bias_mode == 1;
                 float vb_[NV], vs_[NV];
-                float2 st[NV];
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int i = tid + j * NWV * 64, n = n0 + i;
                     const bool live = i < BN && n < p.N;
                     vb_[j] = vs_[j] = 0.f;
-                    st[j] = make_float2(0.f, 1.f);
                     if (col_bias && live) vb_[j] = bias[n];
                     if constexpr (lnsd == 1) {
                         if (live) vs_[j] = p.ln_s[n];
                     }
-                    if constexpr (lnsd == 2) {
-                        if (live) st[j] = *(const float2*)(p.ln_stats + 2 * (bz * p.N + n));
-                    }
-                }
-                constexpr int NRV = ROWV ? (BM + NWV * 64 - 1) / (NWV * 64) : 1;
-                float2 rv_[NRV];
-                if constexpr (ROWV) {
-#pragma unroll
-                    for (int j = 0; j < NRV; ++j) {
-                        const int i = tid + j * NWV * 64, m = m0 + i;
-                        const bool live = i < BM && m < p.M;
-                        rv_[j] = make_float2(live ? p.ln_s[m] : 0.f, (live && bias && p.bias_mode == 2) ? bias[m] : 0.f);
-                    }
                 }
                 // the next tile's first slab (issued during the last K slab) has had a whole slab of MFMAs to land: wait for it
                 // HERE, so that the next K loop does not have to wait on anything this epilogue is about to store
-                // (ring tiles: always - the dead pieces behind a workgroup's last slab must have landed before the staging slot is
-                //  written and before the workgroup gives its LDS back)
-                if (RING || (PERSIST && has_next)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (PERSIST && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int i = tid + j * NWV * 64;
                     if (i < BN) {
                         vbias[i] = vb_[j];
                         if constexpr (lnsd == 1) vaux[i] = vs_[j];
-                        if constexpr (lnsd == 2) *(float2*)(vaux + 2 * i) = st[j];
-                    }
-                }
-                if constexpr (ROWV) {
-#pragma unroll
-                    for (int j = 0; j < NRV; ++j) {
-                        const int i = tid + j * NWV * 64;
-                        if (i < BM) *(float2*)(rowvec + 2 * i) = rv_[j];
                     }
                 }
             }
@@ -930,14 +588,14 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
             //  sits inside run(), behind the first residual loads: their latency overlaps the barrier wait)
             // LayerNorm folded into this GEMM (sdv_hip.h "ln_side"): the weights were pre-multiplied by gamma, so
             //   LN(x) W^T = rstd * (x (gamma o W)^T - mean * s) + (W beta + b),  s = row sums of gamma o W
-            // side 1: (mean, rstd) belong to the output ROW (this lane's m), s to the output column;
-            // side 2 (the transposed V^T projection): (mean, rstd) belong to the output COLUMN, s to the row.
-            constexpr int ln_side = FEAT == 1 ? 1 : (FEAT == 2 ? 2 : 0);
+            // (mean, rstd) belong to the output ROW (this lane's m), s to the output column.  (A column-side form - statistics per
+            //  output column, for a transposed V^T projection - existed in rounds 2-4; the fused QKV projection + row-major V in the
+            //  attention kernel replaced it, DESIGN.md "the round-4 open item".)
+            constexpr int ln_side = FEAT == 1 ? 1 : 0;
 
             // the 4 values of accumulator quad q of tile (nt, mt) with scale / LayerNorm fold / bias applied (GEGLU: W rows
             // are interleaved [16 value | 16 gate] per 32-row MFMA tile, so quads g and g+2 of a lane hold the value and the
             // gate of the SAME 4 channels -> quad g in {0, 1} yields 4 of the n-tile's 16 output columns)
-            float cur_s = 0.f, cur_b = 0.f;   // FEAT 2: (s, bias) of this lane's row in the m-tile being parked (set by park)
             auto quad_vals = [&](bool gg, int nt, int mt, int q, int z, float* v) {   // z: an opaque 0 (see park)
                 if (gg) {
                     const float ln_mu = ln_row[mt][0], ar = alpha * ln_row[mt][1];
@@ -959,7 +617,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 const int nb = wcol0 + nt * 32 + 8 * q + 4 * lhi;
                 const float al = nb < acols ? alpha : 1.f;    // alpha_cols: scale only the leading output columns
                 const float4 bq = *(const float4*)(vbias + (nb - n0) + z);
-                const float brow = ROWV ? cur_b : bm_[mt];
+                const float brow = bm_[mt];
                 const float bvv[4] = {bq.x + brow, bq.y + brow, bq.z + brow, bq.w + brow};
                 if constexpr (ln_side == 1) {
                     const float4 s4 = *(const float4*)(vaux + (nb - n0) + z);
@@ -967,15 +625,6 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     const float ar = al * ln_row[mt][1];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (acc[nt][mt][4 * q + e] - ln_row[mt][0] * sv4[e]) * ar + bvv[e];
-                } else if constexpr (ln_side == 2) {
-                    const float4 st0 = *(const float4*)(vaux + 2 * (nb - n0 + z));       // (mean, rstd) of columns nb, nb+1
-                    const float4 st1 = *(const float4*)(vaux + 2 * (nb - n0 + z) + 4);   //                 nb+2, nb+3
-                    const float mu4[4] = {st0.x, st0.z, st1.x, st1.z}, rs4[4] = {st0.y, st0.w, st1.y, st1.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if constexpr (ROWV) v[e] = __builtin_fmaf(__builtin_fmaf(-mu4[e], cur_s, acc[nt][mt][4 * q + e]), rs4[e] * al, bvv[e]);
-                        else v[e] = (acc[nt][mt][4 * q + e] - mu4[e] * ln_row[mt][0]) * (rs4[e] * al) + bvv[e];
-                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * q + e] * al + bvv[e];
@@ -996,7 +645,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 // covers 8 rows x 128 contiguous bytes instead of 16 rows x 64 - whole cache lines on both streams.
                 // (dense GEMMs only: the conv variants keep ~25 more addressing registers alive across the tile boundary and spilled
                 //  380 - 416 B per lane with the wide pass's 32 + 32 read-back / residual registers)
-                constexpr bool WIDE = SDV_RES_PASS64 && MODE == 1 && DBL && TN >= 2 && (!CONV || SDV_RES_PASS64 == 2);
+                constexpr bool WIDE = MODE == 1 && DBL && TN >= 2 && !CONV;
                 constexpr int RS = WIDE ? 272 : 144;                         // slab row stride in bytes
                 constexpr bool TWO_SLABS = DBL && !WIDE;
                 constexpr int NPT = (MODE == 0 || MODE == 4 || WIDE) ? 2 : (MODE == 2 ? 4 : 1);   // n-tiles per pass
@@ -1005,7 +654,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 constexpr int MAXIT = (F32 && !WIDE) ? 2 : 4;               // 64-lane iterations of the row-major phase
                 // residual rows are fetched DEPTH passes ahead (the fold / statistics variants and the wide passes - twice the rows per
                 // pass - have no registers for a second one)
-                constexpr int DEPTH = ((FEAT == 0 || FEAT == 8 || FEAT == 9) && !WIDE) ? 2 : 1, RING = DEPTH + 1;
+                constexpr int DEPTH = ((FEAT == 0 || FEAT == 8 || FEAT == 9) && !WIDE) ? 2 : 1, RRING = DEPTH + 1;
                 static_assert(!WIDE || 32 * RS <= 2 * SLAB, "the wide fp32 pass must fit the wave's two slabs");
                 auto slab_of = [&](int pi) { return slab0 + (TWO_SLABS ? (pi & 1) * SLAB : 0); };
                 // geometry of pass pi
@@ -1048,11 +697,6 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     //  would otherwise keep the first m-tile's 8 registers per quad alive for the second - they spilled)
                     int z = 0;
                     asm volatile("" : "+v"(z));
-                    if constexpr (ROWV) {
-                        const float2 rv = *(const float2*)(rowvec + 2 * (wm * TM * 32 + mt * 32 + l31 + z));
-                        cur_s = rv.x;
-                        cur_b = rv.y;
-                    }
 #pragma unroll
                     for (int k = 0; k < NPT; ++k) {
                         if (k >= p_cnt(pi)) continue;
@@ -1092,7 +736,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                     }
                 };
                 // residual rows of pass pi, straight in the row-major layout
-                u32x4_t rres[F32 ? RING : 1][MAXIT];
+                u32x4_t rres[F32 ? RRING : 1][MAXIT];
                 auto load_res = [&](int pi) {
                     if constexpr (F32) {
 #pragma unroll
@@ -1101,7 +745,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                             int r, cj;
                             unsigned a, b;
                             item(pi, it, r, cj, a, b);
-                            rres[pi % RING][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)b, soff(pi, p.ldr), 0);
+                            rres[pi % RRING][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)b, soff(pi, p.ldr), 0);
                         }
                     }
                 };
@@ -1193,7 +837,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                             }
                             if (has_r) {
                                 float g[8];
-                                unpack8(__builtin_bit_cast(bf16x8_raw, rres[pi % RING][it]), g);
+                                unpack8(__builtin_bit_cast(bf16x8_raw, rres[pi % RRING][it]), g);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) f[e] += g[e];
                             }
@@ -1321,7 +965,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     }
 
     // ---- fallback epilogue straight from the MFMA registers (odd leading dims / N, e.g. the 77-token V^T) ----
-    if (RING || (PERSIST && has_next)) {   // (as above: the next tile's first slab is waited for here)
+    if (PERSIST && has_next) {   // (as above: the next tile's first slab is waited for here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1474,10 +1118,8 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     }
 }
 
-constexpr int kDefaultConvKOrder = 0;   // sdv_gemm_args.k_order -1 resolves to this (tap-major; see profiles/round3_conv_k_order.txt)
 int g_persistent = 1;   // sdv_gemm_set_persistent(): A/B switch for tools/ (0 = one workgroup per tile, as in round 1)
 int g_grid_limit = 0;   // sdv_gemm_set_grid_limit(): > 0 caps the persistent grid (tests: make small problems WALK tiles)
-int g_walk = 0;         // sdv_gemm_set_walk(): 0 = strided tile order; S > 0 = panel walk, S workgroups per panel
 
 int current_device() {
     int dev = 0;
@@ -1500,11 +1142,11 @@ template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NST, int FEAT =
 int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int TILE_BYTES = (BM + BN) * BK * (FEAT == 8 ? 1 : 2);   // (FEAT 9: two 64-byte-row images = the bf16 tile's bytes)
-    constexpr bool PERSIST = WM * WN == 8 && (NST == 2 || !CONV);      // (see the kernel)
-    constexpr int SLABS = (NST > 2 ? 1 : 2) * WM * WN * 32 * 144;      // the epilogue's staging slabs (alias ONE K-slab buffer)
+    static_assert(NST == 2, "double-buffered K slabs");
+    constexpr bool PERSIST = WM * WN == 8;                             // (see the kernel)
+    constexpr int SLABS = 2 * WM * WN * 32 * 144;                      // the epilogue's staging slabs (alias ONE K-slab buffer)
     constexpr int SLOT = PERSIST && SLABS > TILE_BYTES ? SLABS : TILE_BYTES;
-    constexpr int ROWREG = (FEAT == 2 && BM * 8 > WM * WN * 256) ? BM * 8 : WM * WN * 256;   // FEAT 3 row accumulators / FEAT 2 row operands
-    constexpr int LDS = NST * SLOT + 3 * BN * 4 + ROWREG;              // K-slab buffers + column vectors + row-stat accumulators
+    constexpr int LDS = NST * SLOT + 3 * BN * 4 + WM * WN * 256;       // K-slab buffers + column vectors + FEAT 3's row-stat accumulators
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static unsigned long long attr_set = 0;   // one bit per device: the attribute belongs to the device's copy of the function
     const unsigned long long dev_bit = 1ull << current_device();
@@ -1516,30 +1158,16 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const long long total = (long long)tiles_m * tiles_n * (a.batch > 0 ? a.batch : 1);
     SDV_REQUIRE(total < 0x7fffffffLL, "sdv_gemm_bf16: too many tiles");
-    // (a ring tile's workgroup walks tiles only when every tile has at least NST K slabs: the stream runs NST-1 slabs ahead)
-    const long long nkt = (long long)(a.K / BK) * (CONV ? (a.mode == 4 ? 4 : 9) : 1);
     const int cus = g_grid_limit > 0 && g_grid_limit < num_cus() ? g_grid_limit : num_cus();
-    const bool walk = PERSIST && g_persistent && total > cus && (NST == 2 || nkt >= NST);
+    const bool walk = PERSIST && g_persistent && total > cus;
     dim3 grid((unsigned)(walk ? cus : total), 1, 1);
-    // Panel walk (sdv_hip.h "walk"): only where every workgroup gets the same number of tiles - G/8/S panel slots per XCD, each
-    // XCD's share of the M panels a whole number of rounds over its slots - and there is more than one N tile to walk.
-    sdv_gemm_args aw = a;
-    aw.walk = 0;
-    if (walk && NST == 2 && g_walk > 0 && (a.batch <= 1) && a.mode != 4 && tiles_n >= 2 && (cus & 7) == 0) {
-        int S = g_walk;                                   // workgroups sharing a panel (each walks tiles_n / S N tiles of it)
-        while (S > 1 && (tiles_n % S != 0 || (cus >> 3) % S != 0)) S >>= 1;
-        const int J = (cus >> 3) / S;                     // panel slots per XCD
-        if (J > 0 && tiles_m % (8 * J) == 0) aw.walk = S;
-    }
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>), grid, dim3(WM * WN * 64), LDS, stream, aw);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, BK, CONV, NST, FEAT>), grid, dim3(WM * WN * 64), LDS, stream, a);
     SDV_CHECK_LAUNCH("sdv_gemm_bf16");
     return SDV_OK;
 }
 
-// LN_OK: the tile carries the LayerNorm-fold / row-statistics / fp8 variants; LN2_OK: also the column-side fold (the 256 x 320
-// tile does not: with 160 accumulators its epilogue spilled 276 bytes per lane, and the V^T projections it exists for -
-// M = channels - never pick that tile)
-template <int WM, int WN, int TM, int TN, int BK, int NST = 2, bool LN_OK = false, bool LN2_OK = LN_OK>
+// LN_OK: the tile carries the LayerNorm-fold / row-statistics / fp8 variants
+template <int WM, int WN, int TM, int TN, int BK, int NST = 2, bool LN_OK = false>
 int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
     if (a.fp8) {
         if constexpr (LN_OK && BK == 64 && NST == 2) {   // the same four 8-wave / 4-wave tiles carry the fp8 variants
@@ -1555,19 +1183,14 @@ int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
     if (a.ln_side || a.stats_out) {
         if constexpr (LN_OK) {
             if (a.mode == 0 && a.ln_side == 1 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 1>(a, stream);
-            if constexpr (LN2_OK) {
-                if (a.mode == 0 && a.ln_side == 2 && !a.stats_out) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 2>(a, stream);
-            }
             if (a.mode == 0 && a.ln_side == 0) return launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 3>(a, stream);
         }
-        SDV_REQUIRE(false, "sdv_gemm_bf16: the LayerNorm fold / row statistics exist for dense GEMMs on tiles 1, 6, 7, 9 only (not combined; column-side fold: 1, 7, 9)");
+        SDV_REQUIRE(false, "sdv_gemm_bf16: the LayerNorm fold / row statistics exist for dense GEMMs on tiles 1, 6, 7, 9 only (not combined)");
     }
     if constexpr (WM * WN == 8) {
         if (a.gn_out) {   // the 8-wave tiles carry the GroupNorm-statistics epilogue as a variant of its own (FEAT 4)
-            if constexpr (NST == 2)
-                return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 4>(a, stream)
-                                   : launch_igemm_t<WM, WN, TM, TN, BK, true, NST, 4>(a, stream);
-            SDV_REQUIRE(false, "sdv_gemm_bf16: gn_out is not available on the ring tiles (12, 13)");
+            return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST, 4>(a, stream)
+                               : launch_igemm_t<WM, WN, TM, TN, BK, true, NST, 4>(a, stream);
         }
     }
     return a.mode == 0 ? launch_igemm_t<WM, WN, TM, TN, BK, false, NST>(a, stream)
@@ -1598,12 +1221,6 @@ extern "C" int sdv_gemm_set_grid_limit(int n) {
     return prev;
 }
 
-extern "C" int sdv_gemm_set_walk(int s) {
-    const int prev = g_walk;
-    g_walk = s > 0 ? s : 0;
-    return prev;
-}
-
 static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only) {
     SDV_REQUIRE(args != nullptr, "sdv_gemm_bf16: null args");
     sdv_gemm_args a = *args;
@@ -1619,8 +1236,6 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         SDV_REQUIRE(a.tile == 0 || (a.tile >= 1 && a.tile <= 4) || a.tile == 10 || a.tile == 11, "sdv_gemm_bf16: out_mode exists in the 4-wave tiles only");
         if (a.tile == 0) a.tile = a.N <= 32 ? 10 : (a.N <= 64 ? 11 : 4);   // 256 x 32: one 32-column MFMA tile holds all the outputs; wide: 256 x 128
     }
-    SDV_REQUIRE(a.k_order >= -1 && a.k_order <= 1, "sdv_gemm_bf16: bad k_order %d", a.k_order);
-    if (a.k_order < 0) a.k_order = kDefaultConvKOrder;
     SDV_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "sdv_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SDV_REQUIRE(a.K % 64 == 0, "sdv_gemm_bf16: K=%d must be a multiple of 64", a.K);
     SDV_REQUIRE(a.mode >= 0 && a.mode <= 4, "sdv_gemm_bf16: bad mode %d", a.mode);
@@ -1633,7 +1248,6 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     SDV_REQUIRE(a.C1 % 64 == 0 && a.C1 > 0 && a.C1 <= a.K, "sdv_gemm_bf16: C1=%d must be a multiple of 64 in (0,K]", a.C1);
     SDV_REQUIRE(a.ldx % 8 == 0 && a.ldx2 % 8 == 0 && a.ldw % 8 == 0, "sdv_gemm_bf16: ldx/ldx2/ldw must be multiples of 8");
     SDV_REQUIRE(a.fp8 >= 0 && a.fp8 <= 2, "sdv_gemm_bf16: bad fp8 flag %d", a.fp8);
-    if (a.fp8 == 2) a.k_order = 0;   // (channel-major K order exists for the bf16 / plain fp8 tiles only)
     if (a.fp8) SDV_REQUIRE(a.ldx % 16 == 0 && a.ldx2 % 16 == 0 && a.ldw % 16 == 0, "sdv_gemm_bf16: fp8 rows must be 16-byte multiples");
     if (a.mode != 0) {
         SDV_REQUIRE(a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "sdv_gemm_bf16: bad conv geometry");
@@ -1680,9 +1294,8 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     }
     if (a.bias_mode == 0 && a.bias) a.bias_mode = 1;
     if (a.alpha == 0.f) a.alpha = 1.f;
-    SDV_REQUIRE(a.ln_side >= 0 && a.ln_side <= 2, "sdv_gemm_bf16: bad ln_side %d", a.ln_side);
-    if (a.ln_side) SDV_REQUIRE(a.ln_stats && a.ln_s && !(a.ln_side == 2 && (a.epi == 1 || a.bias_mode == 1)),
-                               "sdv_gemm_bf16: ln_side needs ln_stats + ln_s (column-side: no GEGLU, per-row bias only)");
+    SDV_REQUIRE(a.ln_side == 0 || a.ln_side == 1, "sdv_gemm_bf16: bad ln_side %d (1 = the row-side LayerNorm fold; the column-side form 2 of ABI <= 9 is gone)", a.ln_side);
+    if (a.ln_side) SDV_REQUIRE(a.ln_stats && a.ln_s, "sdv_gemm_bf16: ln_side needs ln_stats + ln_s");
     if (a.ln_side || a.stats_out)
         SDV_REQUIRE((a.ldc & 7) == 0 && ((a.epi == 1 ? a.N >> 1 : a.N) & 7) == 0 && (((uintptr_t)a.C | (uintptr_t)a.bias | (uintptr_t)a.ln_s | (uintptr_t)a.ln_stats) & 15) == 0 &&
                         (!a.R || (a.ldr & 7) == 0) && ((a.sC | a.sR) & 7) == 0 && (((uintptr_t)a.R) & 15) == 0 && a.mode != 4,
@@ -1710,12 +1323,6 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         //  256 x 320 tile as the baseline - 128 x 320 x 32 tiles, two workgroups per CU, 4 or 8 waves each: 0.35 - 0.75x on all 15
         //  transformer shapes; profiles/round4_two_workgroups_per_cu.txt.)
         struct Cand { int id, bm, bn; float rate; };
-        // (14 = the 256 x 320 tile transposed, 320 rows x 256 columns: the column-side LayerNorm fold's V^T projections have M = the
-        //  channel count - 320 / 640 / 1280 - which 256- and 128-row tiles pad by 20-60 %, and it runs them 1.2 - 1.5x faster
-        //  (profiles/round4_vt_tile_ab.txt).  It is NOT a candidate: picked by batch size like every tile, it broke the batch
-        //  invariance of a frame in bench.py's 50-step parity self-check (uint8 max-abs 4-5 between a frame generated in a batch of
-        //  128 and in a batch of 4) although its outputs equal tile 7's bit for bit on every shape tested - unexplained at the end of
-        //  round 4, so the V^T projections stay on tiles 9 / 7 / 1; tile 14 remains selectable (sdv_gemm_args.tile, SDV_VT_TILE).)
         static const Cand cands[] = {{6, 256, 320, 5.0f}, {7, 256, 256, 4.7f}, {9, 128, 320, 4.2f}, {8, 256, 128, 3.3f},
                                      {1, 128, 128, 3.4f}, {2, 128, 64, 2.4f}, {3, 64, 64, 2.0f}};
         // (the 4-wave 256x32 / 256x64 tiles 10 / 11 stay selectable but are not candidates: on the RRDBNet convs the
@@ -1723,9 +1330,7 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         double best = 1e300;
         for (const Cand& c : cands) {
             if (a.epi >= 3 && c.id >= 6) continue;   // extended activations exist in the 4-wave tiles only
-            if (c.id == 14 && !(a.ln_side == 2 && a.mode == 0 && !a.fp8 && !a.stats_out && a.epi == 0)) continue;
-            if ((a.ln_side || a.stats_out || a.fp8) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9 || c.id == 14)) continue;   // LN fold / fp8 tiles
-            if (a.ln_side == 2 && c.id == 6) continue;                                                                   // (no column-side fold there)
+            if ((a.ln_side || a.stats_out || a.fp8) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9)) continue;   // LN fold / fp8 tiles
             const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
             const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
             if (cost < best) {
@@ -1737,37 +1342,28 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     a.tile = 4;   // the kernel reads `tile` as the raster strip width: 8 x 4 blocks of output tiles per XCD wave (1 / 2 / 4 / 8
                   // measured on the UNet: 120.2 / 118.5 / 118.1 / 118.0 ms per forward, profiles/round2_raster_order.txt)
     {
-        static const int kBN[] = {0, 128, 64, 64, 128, 0, 320, 256, 128, 320, 32, 64, 320, 256, 256};
-        static const int kWN[] = {0, 2, 1, 2, 2, 0, 2, 2, 2, 2, 1, 1, 2, 2, 4};
-        SDV_REQUIRE(tile >= 1 && tile <= 14 && kBN[tile], "sdv_gemm_bf16: bad tile %d", tile);
+        static const int kBN[] = {0, 128, 64, 64, 128, 0, 320, 256, 128, 320, 32, 64};
+        static const int kWN[] = {0, 2, 1, 2, 2, 0, 2, 2, 2, 2, 1, 1};
+        SDV_REQUIRE(tile >= 1 && tile <= 11 && kBN[tile], "sdv_gemm_bf16: bad tile %d (1-4, 6-11)", tile);
         a.stats_p = ((a.N + kBN[tile] - 1) / kBN[tile]) * kWN[tile];
     }
     if (plan_only) return a.stats_p;
-    SDV_REQUIRE(!(a.epi >= 3 && ((tile >= 6 && tile <= 9) || tile >= 12)), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
-    if (tile == 14) {   // 320 x 256, 8 waves as 2 x 4: dense GEMMs, plain or with the column-side LayerNorm fold (the V^T projections)
-        SDV_REQUIRE(a.mode == 0 && !a.fp8 && !a.stats_out && !a.gn_out && a.ln_side != 1 && a.epi == 0 && !a.out_mode,
-                    "sdv_gemm_bf16: tile 14 (320 x 256) carries the plain and the column-side-fold dense GEMM only");
-        return a.ln_side == 2 ? launch_igemm_t<2, 4, 5, 2, 64, false, 2, 2>(a, s) : launch_igemm_t<2, 4, 5, 2, 64, false, 2, 0>(a, s);
-    }
+    SDV_REQUIRE(!(a.epi >= 3 && tile >= 6 && tile <= 9), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     SDV_REQUIRE(!(a.epi == 1 && a.R), "sdv_gemm_bf16: GEGLU does not take a residual");
     switch (tile) {
 #ifdef SDV_GEMM_ONLY_TILE6   // (tools: compile the 256 x 320 tile alone for resource / ISA inspection)
-        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true, false>(a, s);
-#elif !defined(SDV_GEMM_RING_ONLY)   // (tools: -DSDV_GEMM_RING_ONLY compiles the ring tiles alone for ISA inspection)
+        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true>(a, s);
+#else
         case 1: return launch_igemm<2, 2, 2, 2, 64, 2, true>(a, s);    // 128 x 128, 4 waves
         case 2: return launch_igemm<4, 1, 1, 2, 64>(a, s);    // 128 x  64
         case 3: return launch_igemm<2, 2, 1, 1, 64>(a, s);    //  64 x  64
         case 4: return launch_igemm<2, 2, 4, 2, 64>(a, s);    // 256 x 128, 4 waves
-        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true, false>(a, s);    // 256 x 320, 8 waves (UNet widths are multiples of 320)
+        case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true>(a, s);    // 256 x 320, 8 waves (UNet widths are multiples of 320)
         case 7: return launch_igemm<4, 2, 2, 4, 64, 2, true>(a, s);    // 256 x 256, 8 waves
         case 8: return launch_igemm<4, 2, 2, 2, 64>(a, s);    // 256 x 128, 8 waves
         case 9: return launch_igemm<4, 2, 1, 5, 64, 2, true>(a, s);    // 128 x 320, 8 waves
         case 10: return launch_igemm<4, 1, 2, 1, 64>(a, s);   // 256 x  32, 4 waves (RRDB growth convs, Cout = 32)
         case 11: return launch_igemm<4, 1, 2, 2, 64>(a, s);   // 256 x  64, 4 waves
-#endif
-#ifndef SDV_GEMM_ONLY_TILE6
-        case 12: return launch_igemm<4, 2, 2, 5, 32, 4, true, false>(a, s);   // 256 x 320, 8 waves, PERSISTENT ring of four 32-wide K tiles
-        case 13: return launch_igemm<4, 2, 2, 4, 32, 4>(a, s);   // 256 x 256, 8 waves, ring
 #endif
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }

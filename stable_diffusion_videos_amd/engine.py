@@ -167,15 +167,15 @@ class _Transformer:
         # The three LayerNorms are folded into the GEMMs they feed (weights.ln_fold / sdv_hip.h ln_side): the GEMM that
         # PRODUCES the normalised tensor also emits its row statistics, the consumers read the un-normalised tensor.
         ln1, ln2, ln3 = ((sd[f"{b}.norm{i}.weight"], sd[f"{b}.norm{i}.bias"]) for i in (1, 2, 3))
+        # attn1.to_q / to_k / to_v as ONE projection [3C, C] = [Wq' ; Wk' ; Wv'] (norm1 folded into all three): the attention
+        # kernel reads Q, K and V straight out of its [tokens, 3C] output - V row-major, transposed in the kernel's LDS read
+        # (sdv_attention_bf16 v_rowmajor) - so the self-attention is 2 launches.  Rounds 2-4 ran a separate TRANSPOSED V^T
+        # projection (column-side LayerNorm fold) per block; DESIGN.md tells what went wrong with it.
         wq, sq, tq = ln_fold(sd[f"{b}.attn1.to_q.weight"], *ln1, None, device, scale=qs)
         wk, sk, tk = ln_fold(sd[f"{b}.attn1.to_k.weight"], *ln1, None, device)
-        self.wqk1 = torch.cat([wq, wk], 0).contiguous()               # [2C, C] = [Wq' ; Wk']
-        self.sqk1, self.tqk1 = torch.cat([sq, sk]).contiguous(), torch.cat([tq, tk]).contiguous()
-        self.wv1, self.sv1, self.tv1 = ln_fold(sd[f"{b}.attn1.to_v.weight"], *ln1, None, device)
-        # token counts that are not a multiple of 8 (2 x 2 latents of the small test configurations) cannot use the aligned
-        # epilogue of the transposed V^T projection: those run norm1 as a kernel of its own
-        self.ln1_plain = (vec(ln1[0], device), vec(ln1[1], device))
-        self.wv1_plain = lin_w(sd[f"{b}.attn1.to_v.weight"], device)
+        wv, sv, tv = ln_fold(sd[f"{b}.attn1.to_v.weight"], *ln1, None, device)
+        self.wqkv1 = torch.cat([wq, wk, wv], 0).contiguous()
+        self.sqkv1, self.tqkv1 = torch.cat([sq, sk, sv]).contiguous(), torch.cat([tq, tk, tv]).contiguous()
         self.wo1, self.bo1 = lin_w(sd[f"{b}.attn1.to_out.0.weight"], device), vec(sd[f"{b}.attn1.to_out.0.bias"], device)
         self.wq2, self.sq2, self.tq2 = ln_fold(sd[f"{b}.attn2.to_q.weight"], *ln2, None, device, scale=qs)
         self.wk2 = lin_w(sd[f"{b}.attn2.to_k.weight"], device)
@@ -189,7 +189,8 @@ class _Transformer:
         self.fold = os.environ.get("SDV_LN_FOLD", "1") != "0"
         if not self.fold:
             self.ln_plain = [(vec(sd[f"{b}.norm{i}.weight"], device), vec(sd[f"{b}.norm{i}.bias"], device)) for i in (1, 2, 3)]
-            self.p_wqk1 = lin_w(torch.cat([sd[f"{b}.attn1.to_q.weight"], sd[f"{b}.attn1.to_k.weight"]], 0), device)
+            self.p_wqkv1 = lin_w(torch.cat([sd[f"{b}.attn1.to_q.weight"], sd[f"{b}.attn1.to_k.weight"],
+                                            sd[f"{b}.attn1.to_v.weight"]], 0), device)
             self.p_wq2 = lin_w(sd[f"{b}.attn2.to_q.weight"], device)
             self.p_wff1 = lin_w(geglu_interleave(sd[f"{b}.ff.net.0.proj.weight"]), device)
             self.p_bff1 = vec(geglu_interleave(sd[f"{b}.ff.net.0.proj.bias"]), device)
@@ -213,10 +214,10 @@ class _Transformer:
         hip.gemm(self.wv2, ctx, ent[1], M=C, N=Lc, K=D, ldx=D, ldw=D, ldc=ldv, batch=nimg, sX=0, sW=Lc * D,
                  sC=C * ldv)
 
-    def __call__(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False, out=None, ctx_of=None):
+    def __call__(self, x, nimg, H, W, shared_prefix: bool = False, out=None, ctx_of=None):
         """``out`` / ``ctx_of=(batch size the context was prepared for, first image)``: this call handles images
         [first, first + nimg) of a larger batch and writes their rows of a larger tensor (UNetEngine._segment)."""
-        out = self._forward(x, nimg, H, W, vt_ws, shared_prefix, out, ctx_of)
+        out = self._forward(x, nimg, H, W, shared_prefix, out, ctx_of)
         _tap(self.name, "transformer", x=x, out=out, nimg=nimg // 2 if shared_prefix else nimg, H=H, W=W, shared_prefix=shared_prefix)
         return out
 
@@ -227,7 +228,7 @@ class _Transformer:
         ctx_k, ctx_vt, Lc = self.ctx[total]
         return ctx_k[first * Lc:(first + nimg) * Lc], ctx_vt[first:first + nimg], Lc
 
-    def _forward(self, x, nimg, H, W, vt_ws: torch.Tensor, shared_prefix: bool = False, out=None, ctx_of=None):
+    def _forward(self, x, nimg, H, W, shared_prefix: bool = False, out=None, ctx_of=None):
         """x: [nimg*HW, C] tokens.  With ``shared_prefix`` x holds only nimg/2 samples whose two CFG copies
         (unconditional / conditional) are still identical: everything up to the cross-attention - GroupNorm, proj_in,
         the whole self-attention, the cross-attention query - is computed ONCE, and the batch doubles where the
@@ -237,24 +238,17 @@ class _Transformer:
         Mb, M = nb * HW, nimg * HW
         scale = dh ** -0.5
         if not self.fold:
-            return self._call_unfolded(x, nimg, H, W, vt_ws, shared_prefix, out, ctx_of)
+            return self._call_unfolded(x, nimg, H, W, shared_prefix, out, ctx_of)
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
         h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)            # + (mean, rstd) of every token for norm1
         _tap(self.name, "tf_in", x=x, out=h, nimg=nb, H=H, W=W)
         h_in = h
-        # --- self attention: LN1 lives inside the Q/K and V^T projections ---
+        # --- self attention: LN1 lives inside the fused Q / K / V projection ---
         qs = hip.q_prescale(dh)       # softmax scale * log2(e), applied by the Q projections before their single rounding
-        qk = hip.linear(h, self.wqk1, self.tqk1, alpha=qs, alpha_cols=C, ln=(st1, self.sqk1))   # [Mb, 2C] = [Q * qs | K]
-        ldv = _round_up(HW, 64)
-        if HW % 8 == 0:
-            hip.gemm(self.wv1, h, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C,
-                     sC=C * ldv, bias=self.tv1, bias_mode=2, ln=(st1, self.sv1), ln_side=2)     # V^T [nb][C][ldv]
-        else:
-            n1 = hip.layernorm(h, *self.ln1_plain)
-            hip.gemm(self.wv1_plain, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C, sC=C * ldv)
+        qkv = hip.linear(h, self.wqkv1, self.tqkv1, alpha=qs, alpha_cols=C, ln=(st1, self.sqkv1))   # [Mb, 3C] = [Q * qs | K | V]
         o = torch.empty((Mb, C), dtype=BF16, device=x.device)
-        hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
-                      scale=scale, k_off=C, q_prescaled=True)
+        hip.attention(qkv, qkv, qkv, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C,
+                      scale=scale, k_off=C, v_off=2 * C, q_prescaled=True, v_rowmajor=True)
         h, st2 = hip.linear(o, self.wo1, self.bo1, residual=h, want_stats=True)
         _tap(self.name, "tf_attn1", x=h_in, out=h, nimg=nb, H=H, W=W)
         h_in = h
@@ -293,7 +287,7 @@ class _Transformer:
         return out
 
 
-    def _call_unfolded(self, x, nimg, H, W, vt_ws, shared_prefix, out=None, ctx_of=None):
+    def _call_unfolded(self, x, nimg, H, W, shared_prefix, out=None, ctx_of=None):
         """The same block with the three LayerNorms as stand-alone kernels (A/B reference for the fold, SDV_LN_FOLD=0)."""
         C, HW, heads, dh = self.C, H * W, self.heads, self.dh
         nb = nimg // 2 if shared_prefix else nimg
@@ -302,12 +296,10 @@ class _Transformer:
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
         h = hip.linear(h, self.w_in, self.b_in)
         n1 = hip.layernorm(h, *self.ln_plain[0])
-        qk = hip.linear(n1, self.p_wqk1, alpha=qs, alpha_cols=C)
-        ldv = _round_up(HW, 64)
-        hip.gemm(self.wv1_plain, n1, vt_ws, M=C, N=HW, K=C, ldx=C, ldw=C, ldc=ldv, batch=nb, sX=0, sW=HW * C, sC=C * ldv)
+        qkv = hip.linear(n1, self.p_wqkv1, alpha=qs, alpha_cols=C)
         o = torch.empty((Mb, C), dtype=BF16, device=x.device)
-        hip.attention(qk, qk, vt_ws, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C,
-                      scale=scale, k_off=C, q_prescaled=True)
+        hip.attention(qkv, qkv, qkv, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C,
+                      scale=scale, k_off=C, v_off=2 * C, q_prescaled=True, v_rowmajor=True)
         h = hip.linear(o, self.wo1, self.bo1, residual=h)
         n2 = hip.layernorm(h, *self.ln_plain[1])
         q = hip.linear(n2, self.p_wq2, alpha=qs)
@@ -395,7 +387,6 @@ class UNetEngine:
         self.conv_out_w = conv_w(sd["conv_out.weight"], dev)
         self.conv_out_b = vec(sd["conv_out.bias"], dev)
         self.groups, self.eps = g, eps
-        self._vt_ws: Dict[tuple, torch.Tensor] = {}
         self.num_steps = 0
         self.fp8_calibrated = False
 
@@ -442,37 +433,17 @@ class UNetEngine:
         for t in self.tfm:
             t.prepare_context(c, nimg, Lc)
 
-    def _vt(self, nimg: int, C: int, HW: int) -> torch.Tensor:
-        """Zero-initialised V^T workspace, shared by all blocks of one (C, HW) shape (stream-ordered)."""
-        key = (nimg, C, HW)
-        if key not in self._vt_ws:
-            self._vt_ws[key] = torch.zeros((nimg, C, _round_up(HW, 64)), dtype=BF16, device=self.device)
-        return self._vt_ws[key]
-
     def release(self, nimg: int):
-        """Free the per-batch-size buffers (cross-attention K / V^T, V^T workspaces) of ``nimg`` samples.  Only when no
+        """Free the per-batch-size buffers (the cross-attention K / V^T of the text context) of ``nimg`` samples.  Only when no
         captured graph of that batch size is alive - they hold raw pointers into these buffers."""
         for t in self.tfm:
             for key in [k for k in t.ctx_by_len if k[0] == nimg]:
                 del t.ctx_by_len[key]
             t.ctx.pop(nimg, None)
-        for key in [k for k in self._vt_ws if k[0] == nimg]:
-            del self._vt_ws[key]
 
     def reserve(self, nimg: int, H: int, W: int):
-        """Allocate the persistent workspaces outside of graph capture."""
-        h, w = H, W
-        for i, blk in enumerate(self.down):
-            for t in blk["attn"]:
-                self._vt(nimg, t.C, h * w)
-            if blk["down"] is not None:
-                h, w = (h + 1) // 2, (w + 1) // 2
-        self._vt(nimg, self.mid[1].C, h * w)
-        for blk in self.up:
-            for t in blk["attn"]:
-                self._vt(nimg, t.C, h * w)
-            if blk["up"] is not None:
-                h, w = 2 * h, 2 * w
+        """(Rounds 1-4 allocated the self-attention's V^T workspaces here, outside of graph capture.  Since the fused QKV projection
+        a forward has no persistent workspace of its own; kept as a no-op for callers that still announce their batch size.)"""
 
     # -- cache blocking ----------------------------------------------------------------------
     # At 128 frames (256 samples) every activation of the 64 x 64 level is 671 MB: each kernel of a ResBlock / transformer
@@ -503,10 +474,9 @@ class UNetEngine:
         if n == 0:
             h = r(h, skip, nb if first else nimg, hh, ww, step_ptr, circ)
             if t is not None:
-                h = t(h, nimg, hh, ww, self._vt(nimg, t.C, HW), shared_prefix=first)
+                h = t(h, nimg, hh, ww, shared_prefix=first)
             return h
         out = torch.empty((nimg * HW, r.cout), dtype=BF16, device=self.device)
-        vt = self._vt(nimg, t.C, HW) if t is not None else None
         parts = []
         for lo in range(0, nimg, n):
             m = min(n, nimg - lo)
@@ -519,7 +489,7 @@ class UNetEngine:
                 r(hs, sk, m, hh, ww, step_ptr, circ, out=o)
             else:
                 y = r(hs, sk, m, hh, ww, step_ptr, circ)
-                t(y, m, hh, ww, vt[:m], out=o, ctx_of=(nimg, lo))
+                t(y, m, hh, ww, out=o, ctx_of=(nimg, lo))
             parts.append(o)
         hip.gn_join(parts, out)
         return out
@@ -565,7 +535,7 @@ class UNetEngine:
                 skips.append(h)
         r0, t0, r1 = self.mid
         h = r0(h, None, nimg, hh, ww, step_ptr, circ)
-        h = t0(h, nimg, hh, ww, self._vt(nimg, t0.C, hh * ww))
+        h = t0(h, nimg, hh, ww)
         h = r1(h, None, nimg, hh, ww, step_ptr, circ)
         for bi, blk in enumerate(self.up):
             for j, r in enumerate(blk["res"]):

@@ -38,11 +38,11 @@ class GemmArgs(C.Structure):
         ("alpha_cols", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
         ("fp8", C.c_int32), ("out_mode", C.c_int32), ("out_f32", C.c_void_p), ("out_u8", C.c_void_p),
-        ("k_order", C.c_int32), ("walk", C.c_int32), ("gn_out", C.c_void_p), ("gn_ld", C.c_int32),
+        ("gn_out", C.c_void_p), ("gn_ld", C.c_int32),
     ]
 
 
-ABI_VERSION = 9     # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 10    # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -52,9 +52,8 @@ _SIGNATURES = {
     "sdv_gemm_stats_slots": (C.c_int, [C.POINTER(GemmArgs)]),
     "sdv_gemm_set_persistent": (C.c_int, [C.c_int]),
     "sdv_gemm_set_grid_limit": (C.c_int, [C.c_int]),
-    "sdv_gemm_set_walk": (C.c_int, [C.c_int]),
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
-    "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_groupnorm_finalize": (C.c_int, ([C.c_void_p] + [C.c_int32] * 4 + [C.c_int64]) * 2 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),
@@ -67,7 +66,6 @@ _SIGNATURES = {
     "sdv_layernorm_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sdv_conv3x3_cin_small": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
     "sdv_im2col3x3_c4": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
-    "sdv_conv3x3_cout_small": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
     "sdv_latent_affine": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "sdv_slerp_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sdv_slerp_batch": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
@@ -146,7 +144,6 @@ FP8_MAX = 448.0
 
 _zero_pages = {}
 FP8_MX = int(os.environ.get("SDV_FP8_MX", "1"))            # developer knob for A/B: 0 = fp8 operands on the plain (bf16-rate) fp8 MFMA
-K_ORDER = int(os.environ.get("SDV_CONV_K_ORDER", "-1"))    # developer knob for A/B (tools/conv_order_ab.py); -1 = library default
 # Test / tools knob: launches that leave the tile to the cost model (tile=0) are forced onto this tile where it exists for them
 # (6 = the persistent 256 x 320 tile).  With it - and sdv_gemm_set_grid_limit - a 2-sample forward runs the SAME tile code paths as
 # the 256-sample benchmark forward, so they can be put under the oracle's block-wise absolute gate (tests/test_blockwise_gpu.py).
@@ -199,13 +196,9 @@ def zero_page(device) -> torch.Tensor:
 # GEMM / conv
 # ------------------------------------------------------------------------------------------------
 _GEMM_INTS = ("M", "N", "K", "ldx", "ldw", "ldc", "ldr", "C1", "ldx2", "epi", "mode", "Hin", "Win", "Hout", "Wout", "circular", "batch",
-              "sX", "sW", "sC", "sR", "bias_mode", "bias_step_stride", "tile", "x_off", "w_off", "out_off", "alpha_cols", "ln_side",
-              "out_mode", "k_order")
+              "sX", "sW", "sC", "sR", "bias_mode", "bias_step_stride", "tile", "x_off", "w_off", "out_off", "alpha_cols", "out_mode")
 
 
-# Developer knob: tile of the column-side-fold (V^T) launches, 0 = cost model.  FORCE_TILE (the 256 x 320 tile) cannot carry them; they
-# are bit-identical across tiles by construction (explicit FMAs in the fold), which the batch-128 parity checks rely on.
-VT_TILE = int(os.environ.get("SDV_VT_TILE", "0"))
 GN_EPILOGUE = os.environ.get("SDV_GN_EPILOGUE", "1") != "0"     # A/B knob: 0 = every GroupNorm runs its own statistics pass
 
 
@@ -283,7 +276,6 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
     a.R = _ptr(residual, BF16, "R")
     a.C = _ptr(out, BF16, "C") + 2 * g["out_off"] if out is not None else None
     a.out_mode, a.out_f32, a.out_u8 = g["out_mode"], _ptr(out_f32, F32, "out_f32"), _ptr(out_u8, torch.uint8, "out_u8")
-    a.k_order = K_ORDER if g["k_order"] < 0 else g["k_order"]
     a.step_ptr = _ptr(step_ptr, torch.int32, "step_ptr")
     a.zero_page = zero_page(x.device).data_ptr()
     a.sX, a.sW, a.sC, a.sR = g["sX"], g["sW"], g["sC"], g["sR"]
@@ -292,12 +284,10 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
     a.mode, a.Hin, a.Win, a.Hout, a.Wout, a.circular = mode, g["Hin"], g["Win"], g["Hout"], g["Wout"], g["circular"]
     a.epi, a.bias_mode, a.bias_step_stride = epi, (g["bias_mode"] if bias is not None else 0), g["bias_step_stride"]
     a.batch, a.tile, a.alpha, a.alpha_cols = batch, g["tile"], alpha, g["alpha_cols"]
-    if FORCE_TILE and not g["tile"] and not g["out_mode"] and epi < 3 and not (ln_stats is not None and g["ln_side"] == 2):
+    if FORCE_TILE and not g["tile"] and not g["out_mode"] and epi < 3:
         a.tile = FORCE_TILE
-    if VT_TILE and not g["tile"] and ln_stats is not None and g["ln_side"] == 2:
-        a.tile = VT_TILE
     if ln_stats is not None:
-        a.ln_stats, a.ln_s, a.ln_side = _ptr(ln_stats, F32, "ln_stats"), _ptr(ln_s, F32, "ln_s"), g["ln_side"]
+        a.ln_stats, a.ln_s, a.ln_side = _ptr(ln_stats, F32, "ln_stats"), _ptr(ln_s, F32, "ln_s"), 1
     if gn_out is not None:
         a.gn_out, a.gn_ld = _ptr(gn_out, F32, "gn_out"), gn_out.shape[-1]
     partials = None
@@ -341,9 +331,9 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          epi: int = 0, mode: int = 0, Hin: int = 0, Win: int = 0, Hout: int = 0, Wout: int = 0,
          circular: bool = False, batch: int = 1, sX: int = 0, sW: int = 0, sC: int = 0, sR: int = 0,
          step_ptr: Optional[torch.Tensor] = None, bias_step_stride: int = 0, tile: int = 0,
-         x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None, ln_side: int = 1,
+         x_off: int = 0, w_off: int = 0, out_off: int = 0, alpha_cols: int = 0, ln=None,
          want_stats: bool = False, ln_eps: float = 1e-5, out_mode: int = 0, out_f32: Optional[torch.Tensor] = None,
-         out_u8: Optional[torch.Tensor] = None, k_order: int = -1, gn_hw: int = 0):
+         out_u8: Optional[torch.Tensor] = None, gn_hw: int = 0):
     """``sdv_gemm_bf16`` through ``torch.ops.sdv.k_igemm`` (element offsets x_off / w_off / out_off select sub-matrices).
     ``out_mode`` 1 / 2: fp32 output / image epilogue into ``out_f32`` / ``out_u8`` (``out`` may be None), see sdv_hip.h.
     ``ln=(stats, s)``: LayerNorm folded into this GEMM (sdv_hip.h): ``stats`` fp32 [rows, 2] = (mean, rstd) from
@@ -352,7 +342,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     ``gn_hw`` > 0: the output is an NHWC image tensor with ``gn_hw`` pixels per image whose next consumer is a GroupNorm - where the
     launch qualifies (``gn_epilogue_ok``) the epilogue also emits the per-channel statistics and ``out._sdv_gn`` carries them."""
     ints = [M, N, K, ldx, ldw, ldc, ldr, C1, ldx2, epi, mode, Hin, Win, Hout, Wout, int(circular), batch, sX, sW, sC, sR, bias_mode,
-            bias_step_stride, tile, x_off, w_off, out_off, alpha_cols, ln_side, out_mode, k_order]
+            bias_step_stride, tile, x_off, w_off, out_off, alpha_cols, out_mode]
     gn_out = None
     nb = max(batch, 1)
     if gn_hw and out_off == 0 and gn_epilogue_ok(M=M, N=N, epi=epi, mode=mode, ldc=ldc, ldr=ldr, out=out, bias=bias, residual=residual,
@@ -449,26 +439,30 @@ def upconv3x3_phase(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tens
 # ------------------------------------------------------------------------------------------------
 # attention / norms
 # ------------------------------------------------------------------------------------------------
-def _attention_impl(q, k, vt, out, ints, scale, causal, q_prescaled):
-    B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off = ints
+def _attention_impl(q, k, vt, out, ints, scale, causal, q_prescaled, v_rowmajor):
+    B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off, v_off = ints
     lib = load()
-    qp, kp, vp, op = _ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off, _ptr(vt, BF16, "Vt"), _ptr(out, BF16, "O")
+    qp, kp, op = _ptr(q, BF16, "Q") + 2 * q_off, _ptr(k, BF16, "K") + 2 * k_off, _ptr(out, BF16, "O")
+    vp = _ptr(vt, BF16, "V") + 2 * v_off
     _launch("attention", dict(B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, flops=4.0 * B * H * Lq * Lk * dh),
             lambda: _check(lib.sdv_attention_bf16(qp, kp, vp, op, B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, scale, int(causal),
-                                                  int(q_prescaled), _stream()),
+                                                  int(q_prescaled), int(v_rowmajor), _stream()),
                            "sdv_attention_bf16"))
 
 
 _k_attention = _defop("k_attention(Tensor q, Tensor k, Tensor vt, Tensor(a!) out, int[] ints, float scale, bool causal, "
-                      "bool q_prescaled) -> ()", _attention_impl)
+                      "bool q_prescaled, bool v_rowmajor) -> ()", _attention_impl)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Lq: int,
               Lk: int, dh: int, ldq: int, ldk: int, ldv: int, ldo: int, scale: float, q_off: int = 0, k_off: int = 0,
-              causal: bool = False, q_prescaled: bool = False):
+              v_off: int = 0, causal: bool = False, q_prescaled: bool = False, v_rowmajor: bool = False):
     """softmax(Q K^T scale) V (``torch.ops.sdv.k_attention``).  ``q_prescaled``: Q already holds q * scale * log2(e)
-    (``LOG2E_SCALE(dh)`` applied as the ``alpha`` of its projection GEMM, one bf16 rounding in total) and ``scale`` is ignored."""
-    _k_attention(q, k, vt, out, [B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off], float(scale), bool(causal), bool(q_prescaled))
+    (``LOG2E_SCALE(dh)`` applied as the ``alpha`` of its projection GEMM, one bf16 rounding in total) and ``scale`` is ignored.
+    ``vt``: V transposed [B][H*dh][ldv] (the text context's V^T) or, with ``v_rowmajor``, V as a projection wrote it -
+    [B*Lk][ldv] rows, head h at columns v_off + [h*dh, (h+1)*dh): the V third of a fused [Q | K | V] projection."""
+    _k_attention(q, k, vt, out, [B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off, v_off], float(scale), bool(causal),
+                 bool(q_prescaled), bool(v_rowmajor))
 
 
 _fp8_sat_ref: Optional[torch.Tensor] = None
@@ -731,22 +725,6 @@ def _axpby_impl(a, b, out, alpha, beta):
 _k_axpby = _defop("k_axpby(Tensor a, Tensor b, Tensor(a!) out, float alpha, float beta) -> ()", _axpby_impl)
 
 
-def _conv3x3_cout_small_impl(x, w, bias, out_f32, out_u8, nimg, H, W, out_mode, circular):
-    lib = load()
-    Cin = x.shape[1]
-    Cout = w.shape[0]
-    xp, wp, bp, fp, up = _ptr(x, BF16, "X"), _ptr(w, BF16, "W"), _ptr(bias, F32), _ptr(out_f32, F32), _ptr(out_u8, torch.uint8)
-    _launch("conv_cout_small", dict(flops=18.0 * nimg * H * W * Cin * Cout, bytes=2.0 * nimg * H * W * Cin),
-            lambda: _check(lib.sdv_conv3x3_cout_small(xp, wp, bp, fp, up, nimg, H, W, Cin, Cout, out_mode, int(circular),
-                                                      _stream()), "sdv_conv3x3_cout_small"))
-
-
-_k_conv3x3_cout_small = _defop("k_conv3x3_cout_small(Tensor x, Tensor w, Tensor? bias, Tensor(a!)? out_f32, Tensor(b!)? out_u8, int nimg, "
-                               "int H, int W, int out_mode, bool circular) -> ()", _conv3x3_cout_small_impl)
-
-
-def conv3x3_cout_small(x, w, bias, *, nimg, H, W, out_mode=0, out_f32=None, out_u8=None, circular=False):
-    _k_conv3x3_cout_small(x, w, bias, out_f32, out_u8, nimg, H, W, out_mode, bool(circular))
 
 
 def _latent_affine_impl(x, wpq, bias, in_scale, out, npix, Cn):

@@ -74,7 +74,6 @@ class CLIPTextEngine:
         self.state_dict_ = state_dict
         self.device = torch.device("cpu")
         self._w = None
-        self._vt = {}
 
     def state_dict(self):
         return self.state_dict_
@@ -96,15 +95,15 @@ class CLIPTextEngine:
                 w["layers"].append(dict(
                     ln1=(vec(sd[p + "layer_norm1.weight"], device), vec(sd[p + "layer_norm1.bias"], device)),
                     ln2=(vec(sd[p + "layer_norm2.weight"], device), vec(sd[p + "layer_norm2.bias"], device)),
-                    wqk=lin_w(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"]], 0), device),
-                    # the Q half of the bias carries the softmax scale * log2(e) that the projection's alpha puts on Q
-                    bqk=vec(torch.cat([sd[a + "q_proj.bias"].float() * qs, sd[a + "k_proj.bias"].float()], 0), device),
-                    wv=lin_w(sd[a + "v_proj.weight"], device), bv=vec(sd[a + "v_proj.bias"], device),
+                    # q / k / v as one projection [3D, D]; the attention kernel reads V row-major out of its output
+                    wqkv=lin_w(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0), device),
+                    # the Q third of the bias carries the softmax scale * log2(e) that the projection's alpha puts on Q
+                    bqkv=vec(torch.cat([sd[a + "q_proj.bias"].float() * qs, sd[a + "k_proj.bias"].float(),
+                                        sd[a + "v_proj.bias"].float()], 0), device),
                     wo=lin_w(sd[a + "out_proj.weight"], device), bo=vec(sd[a + "out_proj.bias"], device),
                     w1=lin_w(sd[p + "mlp.fc1.weight"], device), b1=vec(sd[p + "mlp.fc1.bias"], device),
                     w2=lin_w(sd[p + "mlp.fc2.weight"], device), b2=vec(sd[p + "mlp.fc2.bias"], device)))
             self._w = w
-            self._vt.clear()
         self.device = device
         return self
 
@@ -124,20 +123,14 @@ class CLIPTextEngine:
             raise IndexError(f"token id outside [0, {c.vocab_size})")
         D, H = c.hidden_size, c.num_attention_heads
         dh = D // H
-        ldv = (L + 63) // 64 * 64
         epi = 4 if c.hidden_act == "quick_gelu" else 5
-        vt = self._vt.get((B, L))
-        if vt is None:                     # V^T workspace; the columns >= L are never written and must stay finite (zero)
-            vt = self._vt[(B, L)] = torch.zeros((B, D, ldv), dtype=torch.bfloat16, device=self.device)
         x = hip.embed_tokens(ids, w["tok"], w["pos"])                                          # [B*L, D]
         o = torch.empty_like(x)
         for lw in w["layers"]:
             h = hip.layernorm(x, *lw["ln1"], eps=1e-5)
-            qk = hip.linear(h, lw["wqk"], lw["bqk"], alpha=hip.q_prescale(dh), alpha_cols=D)   # [M, 2D] = [Q * qs | K]
-            hip.gemm(lw["wv"], h, vt, M=D, N=L, K=D, ldx=D, ldw=D, ldc=ldv, bias=lw["bv"], bias_mode=2, batch=B,
-                     sX=0, sW=L * D, sC=D * ldv)                                               # V^T (+ bias per channel)
-            hip.attention(qk, qk, vt, o, B=B, H=H, Lq=L, Lk=L, dh=dh, ldq=2 * D, ldk=2 * D, ldv=ldv, ldo=D,
-                          scale=dh ** -0.5, k_off=D, causal=True, q_prescaled=True)
+            qkv = hip.linear(h, lw["wqkv"], lw["bqkv"], alpha=hip.q_prescale(dh), alpha_cols=D)   # [M, 3D] = [Q * qs | K | V]
+            hip.attention(qkv, qkv, qkv, o, B=B, H=H, Lq=L, Lk=L, dh=dh, ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D,
+                          scale=dh ** -0.5, k_off=D, v_off=2 * D, causal=True, q_prescaled=True, v_rowmajor=True)
             x = hip.linear(o, lw["wo"], lw["bo"], residual=x)
             h = hip.layernorm(x, *lw["ln2"], eps=1e-5)
             f = hip.linear(h, lw["w1"], lw["b1"], epi=epi)

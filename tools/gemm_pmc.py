@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """A handful of igemm launches on the UNet's shapes - the workload for `rocprofv3 --pmc ...` passes over single kernels.
-usage: gemm_pmc.py [tile ...]   (default tiles 6 12)"""
+usage: gemm_pmc.py [tile ...]   (default tile 6)"""
 import sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stable_diffusion_videos_amd import hip  # noqa: E402
 
-tiles = [int(t) for t in sys.argv[1:]] or [6, 12]
+tiles = [int(t) for t in sys.argv[1:]] or [6]
 dev = torch.device("cuda")
 hip.load()
 nimg = 128

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stable_diffusion_videos_amd import hip  # noqa: E402
 
-TILES = {1: "128x128", 2: "128x64", 3: "64x64", 6: "256x320", 7: "256x256", 8: "256x128", 9: "128x320", 12: "256x320r", 13: "256x256r"}
+TILES = {1: "128x128", 2: "128x64", 3: "64x64", 6: "256x320", 7: "256x256", 8: "256x128", 9: "128x320"}
 
 
 def bench(fn, reps=5):

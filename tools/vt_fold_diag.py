@@ -17,11 +17,67 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from stable_diffusion_videos_amd import hip  # noqa: E402
+import ctypes as C  # noqa: E402
+
+# The tool talks to ROUND-4 builds (ABI 9) through its own copy of that ABI's sdv_gemm_args layout: the product's binding
+# (stable_diffusion_videos_amd/hip.py, ABI 10) no longer has the column-side fold.
+
+
+class GemmArgsR4(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("X2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+        ("C", C.c_void_p), ("step_ptr", C.c_void_p), ("zero_page", C.c_void_p),
+        ("sX", C.c_int64), ("sW", C.c_int64), ("sC", C.c_int64), ("sR", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("ldx", C.c_int32), ("ldx2", C.c_int32), ("C1", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32),
+        ("ldr", C.c_int32),
+        ("mode", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("circular", C.c_int32),
+        ("epi", C.c_int32), ("bias_mode", C.c_int32), ("bias_step_stride", C.c_int32),
+        ("batch", C.c_int32), ("tile", C.c_int32), ("alpha", C.c_float),
+        ("div_hw_mul", C.c_uint32), ("div_hw_shr", C.c_uint32), ("div_w_mul", C.c_uint32), ("div_w_shr", C.c_uint32),
+        ("alpha_cols", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
+        ("fp8", C.c_int32), ("out_mode", C.c_int32), ("out_f32", C.c_void_p), ("out_u8", C.c_void_p),
+        ("k_order", C.c_int32), ("walk", C.c_int32), ("gn_out", C.c_void_p), ("gn_ld", C.c_int32),
+    ]
+
+
+class _R4:
+    """Minimal stand-in for the round-4 ``hip`` module: load(), lib_path(), gemm() of the column-side fold, SdvHipError."""
+    SdvHipError = RuntimeError
+
+    def __init__(self):
+        self.path = os.environ.get("SDV_HIP_LIB", str(Path(__file__).resolve().parent / "ubench" / "libsdv_r4.so"))
+        self.lib = None
+
+    def load(self):
+        self.lib = C.CDLL(self.path)
+        self.lib.sdv_abi_version.restype = C.c_int
+        assert self.lib.sdv_abi_version() == 9, "vt_fold_diag.py needs a round-4 (ABI 9) build: SDV_HIP_LIB=tools/ubench/libsdv_r4*.so"
+        self.lib.sdv_gemm_bf16.restype = C.c_int
+        self.lib.sdv_gemm_bf16.argtypes = [C.POINTER(GemmArgsR4), C.c_void_p]
+        self.lib.sdv_last_error.restype = C.c_char_p
+
+    def lib_path(self):
+        return self.path
+
+    def gemm(self, x, w, out, *, M, N, K, ldx, ldw, ldc, batch, sX, sW, sC, bias, bias_mode, ln, ln_side, tile):
+        a = GemmArgsR4()
+        a.X, a.W, a.C, a.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr()
+        a.M, a.N, a.K, a.ldx, a.ldw, a.ldc, a.batch, a.sX, a.sW, a.sC = M, N, K, ldx, ldw, ldc, batch, sX, sW, sC
+        a.bias_mode, a.tile, a.alpha, a.k_order = bias_mode, tile, 1.0, -1
+        a.ln_stats, a.ln_s, a.ln_side = ln[0].data_ptr(), ln[1].data_ptr(), ln_side
+        rc = self.lib.sdv_gemm_bf16(C.byref(a), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(self.lib.sdv_last_error().decode(errors="replace"))
+
+
+hip = _R4()
 
 REPS = int(os.environ.get("VT_DIAG_REPS", "12"))
-TILES = (1, 7, 9, 14)
+TILES = tuple(int(t) for t in os.environ.get("VT_DIAG_TILES", "1,7,9,14").split(","))
+LEVELS = os.environ.get("VT_DIAG_LEVELS", "64,32,16").split(",")
 
 
 def operands(nimg, L, C, dev):
@@ -42,8 +98,10 @@ def operands(nimg, L, C, dev):
 def main():
     dev = torch.device("cuda")
     hip.load()
-    print(f"library: {hip.lib_path()}   reps {REPS}", flush=True)
+    print(f"library: {hip.lib_path()}   reps {REPS}   tiles {TILES}", flush=True)
     for H, C in ((64, 320), (32, 640), (16, 1280)):
+        if str(H) not in LEVELS:
+            continue
         L = H * H
         for nimg in (8, 64):
             x, w, st, sv, tv = operands(nimg, L, C, dev)
