@@ -206,11 +206,20 @@ class GnStats:
     """GroupNorm statistics that left the producing igemm's epilogue (sdv_gemm_args.gn_out): ``p`` fp32 [blocks, 2, C] of
     (sum, sumsq) per 32-row block and channel of a tensor of ``nimg`` images with ``HW`` pixels each; ``nrep`` repetitions
     ``rep_stride`` blocks apart (the four phases of a phase-form up-conv).  Travels as ``tensor._sdv_gn`` with the tensor the
-    producer returned; ``groupnorm`` uses it instead of a statistics pass when it matches what it is asked to normalise."""
-    __slots__ = ("p", "C", "nimg", "HW", "bpi", "nrep", "rep_stride")
+    producer returned; ``groupnorm`` uses it instead of a statistics pass when it matches what it is asked to normalise - same
+    geometry AND the tensor's version counter still where it was when the statistics were attached (``ver``): any in-place torch
+    writer since (``copy_``, ``add_``, an ``out=`` op) makes ``groupnorm`` fall back to its own statistics pass."""
+    __slots__ = ("p", "C", "nimg", "HW", "bpi", "nrep", "rep_stride", "ver")
 
-    def __init__(self, p, C, nimg, HW, bpi, nrep, rep_stride):
-        self.p, self.C, self.nimg, self.HW, self.bpi, self.nrep, self.rep_stride = p, C, nimg, HW, bpi, nrep, rep_stride
+    def __init__(self, p, C, nimg, HW, bpi, nrep, rep_stride, ver=-1):
+        self.p, self.C, self.nimg, self.HW, self.bpi, self.nrep, self.rep_stride, self.ver = p, C, nimg, HW, bpi, nrep, rep_stride, ver
+
+
+def _ver(t: torch.Tensor) -> int:
+    try:
+        return t._version
+    except RuntimeError:          # inference tensors do not track versions: nothing to compare, the geometry check stands alone
+        return -1
 
 
 def gn_repeat(t_src: torch.Tensor, t_dst: torch.Tensor, times: int):
@@ -218,7 +227,7 @@ def gn_repeat(t_src: torch.Tensor, t_dst: torch.Tensor, times: int):
     source's, repeated."""
     g = getattr(t_src, "_sdv_gn", None)
     if g is not None and g.nrep == 1:
-        t_dst._sdv_gn = GnStats(torch.cat([g.p] * times), g.C, g.nimg * times, g.HW, g.bpi, 1, 0)
+        t_dst._sdv_gn = GnStats(torch.cat([g.p] * times), g.C, g.nimg * times, g.HW, g.bpi, 1, 0, _ver(t_dst))
 
 
 def gn_slice(t: torch.Tensor, first_img: int, n_img: int, HW: int) -> torch.Tensor:
@@ -229,10 +238,10 @@ def gn_slice(t: torch.Tensor, first_img: int, n_img: int, HW: int) -> torch.Tens
     if g is not None and g.HW == HW:
         if g.nrep == 1:
             p = g.p[first_img * g.bpi:(first_img + n_img) * g.bpi]
-            out._sdv_gn = GnStats(p, g.C, n_img, HW, g.bpi, 1, 0)
+            out._sdv_gn = GnStats(p, g.C, n_img, HW, g.bpi, 1, 0, g.ver)
         else:
             p = g.p.view(g.nrep, g.rep_stride, 2, g.C)[:, first_img * g.bpi:(first_img + n_img) * g.bpi].contiguous()
-            out._sdv_gn = GnStats(p.view(-1, 2, g.C), g.C, n_img, HW, g.bpi, g.nrep, n_img * g.bpi)
+            out._sdv_gn = GnStats(p.view(-1, 2, g.C), g.C, n_img, HW, g.bpi, g.nrep, n_img * g.bpi, g.ver)
     return out
 
 
@@ -240,7 +249,7 @@ def gn_join(parts, whole: torch.Tensor):
     """The statistics of ``whole`` from those of its consecutive image chunks ``parts`` (all produced with nrep == 1)."""
     gs = [getattr(t, "_sdv_gn", None) for t in parts]
     if gs and all(g is not None and g.nrep == 1 for g in gs):
-        whole._sdv_gn = GnStats(torch.cat([g.p for g in gs]), gs[0].C, sum(g.nimg for g in gs), gs[0].HW, gs[0].bpi, 1, 0)
+        whole._sdv_gn = GnStats(torch.cat([g.p for g in gs]), gs[0].C, sum(g.nimg for g in gs), gs[0].HW, gs[0].bpi, 1, 0, _ver(whole))
 
 
 def gn_epilogue_ok(*, M, N, epi, mode, ldc, ldr, out, bias, residual, fp8, ln, want_stats, out_mode, HW_out, batch, sC, sR) -> bool:
@@ -356,7 +365,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     if gn_out is not None:
         rows_per_image = gn_hw // 4 if mode == 4 else gn_hw
         nimg = (M if mode == 4 else nb * M) // rows_per_image
-        out._sdv_gn = GnStats(gn_out, N, nimg, gn_hw, rows_per_image // 32, 4 if mode == 4 else 1, (M // 32) if mode == 4 else 0)
+        out._sdv_gn = GnStats(gn_out, N, nimg, gn_hw, rows_per_image // 32, 4 if mode == 4 else 1, (M // 32) if mode == 4 else 0, _ver(out))
     elif out is not None and hasattr(out, "_sdv_gn"):
         del out._sdv_gn
     return st if want_stats else None
@@ -582,7 +591,8 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg:
     g2 = getattr(x2, "_sdv_gn", None) if (x2 is not None and GN_EPILOGUE) else None
 
     def fits(g, t):
-        return g is not None and g.nimg == nimg and g.HW == HW and g.C == t.shape[1] and t.shape[0] == nimg * HW
+        return (g is not None and g.nimg == nimg and g.HW == HW and g.C == t.shape[1] and t.shape[0] == nimg * HW
+                and g.ver == _ver(t))
 
     geo = [0, 1, 0, 0, 1, 0]
     p1 = p2 = None

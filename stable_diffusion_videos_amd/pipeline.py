@@ -121,6 +121,7 @@ class StableDiffusionWalkPipeline:
         self.cfg_shared_prefix = os.environ.get("SDV_NO_CFG_SHARED", "0") != "1"   # see UNetEngine.forward
         self._device = torch.device("cpu")
         self._graphs: Dict[tuple, dict] = {}
+        self._graph_pool = None            # the private memory pool every captured step allocates from (see _capture)
         self.max_cached_graphs = 4         # LRU bound on captured denoise-step graphs (each has its own memory pool)
         self._uncond_cache: Dict[str, torch.Tensor] = {}
         self._sched_cache: Dict[tuple, tuple] = {}
@@ -354,7 +355,19 @@ class StableDiffusionWalkPipeline:
         else:
             hip.set_fp8_saturation_counter(None)
             self._fp8_sat = None
-            self._graphs.clear()      # (their launches still carry the old counter's address)
+        # steps captured before the switch carry the OLD counter address (or none): replayed, they would count into a freed tensor
+        # or read as "nothing clamped" - both directions drop them
+        self._drop_graphs()
+
+    def _drop_graphs(self):
+        """Forget every captured step the way the LRU eviction does: the graph object goes, and so do the per-batch-size
+        cross-attention buffers it held raw pointers into."""
+        sizes = {k[1] for k in self._graphs}
+        for ent in self._graphs.values():
+            ent["graph"] = None
+        self._graphs.clear()
+        for nimg in sizes:
+            self.unet.release(nimg)
 
     def fp8_saturated(self) -> int:
         """Clamped e4m3 conversions since ``enable_fp8_saturation_check()`` (host synchronising)."""
@@ -453,25 +466,39 @@ class StableDiffusionWalkPipeline:
             hip.step_counter_add(ent["step"], 1)
 
         ent["one_step"] = one_step
-        if self.use_graphs:
-            t0 = time.perf_counter()
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                one_step()                       # warm-up: lazy allocations / attribute sets happen here
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            g = torch.cuda.CUDAGraph()
-            # with a process group alive its watchdog thread may touch the runtime while this thread captures: only this
-            # thread's calls (kernel launches through the C ABI) need to be capture-safe
-            mode = "thread_local" if parallel.world()[1] > 1 else "global"
-            with torch.cuda.graph(g, capture_error_mode=mode):
-                one_step()
-            ent["graph"] = g
-            self.last_graph_build = {"nimg": nimg, "warmup_s": t1 - t0, "capture_s": time.perf_counter() - t1}
+        # The step is captured by ``_capture`` right AFTER its first eager execution - which is the first REAL denoise step of the
+        # first call at this key (lazy allocations / attribute sets happen there), not a throw-away warm-up on zero-filled buffers.
+        ent["capture_pending"] = bool(self.use_graphs)
         self._graphs[key] = ent
         return ent
+
+    def _capture(self, ent: dict):
+        """Capture ``ent``'s denoise step into a hipGraph (nothing executes: the static buffers keep the state the eager step
+        left).  Not through the ``torch.cuda.graph`` context manager: its ``__enter__`` runs ``torch.cuda.empty_cache()``, which
+        hands every cached block of the allocator back to the driver - 0.9 s for a 16-frame capture that followed a 60-frame call,
+        1.7 s of the 2.15 s "cold start" the round-4 bench line showed (profiles/round5_cold_start_probe_before.txt); the capture
+        itself is 14 ms.  All captured steps share ONE private memory pool: their intermediates are dead when a replay ends and
+        two steps never run concurrently, so a new batch size costs the pool only what it needs beyond the largest so far."""
+        t0 = time.perf_counter()
+        dev = self.device
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        g = torch.cuda.CUDAGraph()
+        # with a process group alive its watchdog thread may touch the runtime while this thread captures: only this
+        # thread's calls (kernel launches through the C ABI) need to be capture-safe
+        mode = "thread_local" if parallel.world()[1] > 1 else "global"
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g.capture_begin(pool=self._graph_pool, capture_error_mode=mode)
+            try:
+                ent["one_step"]()
+            finally:
+                g.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        ent["graph"] = g
+        ent["capture_pending"] = False
+        self.last_graph_build = {"capture_s": time.perf_counter() - t0}
 
     @torch.no_grad()
     def __call__(self, prompt: Optional[Union[str, List[str]]] = None, height: Optional[int] = None,
@@ -591,6 +618,8 @@ class StableDiffusionWalkPipeline:
                 ent["graph"].replay()
             else:
                 ent["one_step"]()
+                if ent.get("capture_pending"):
+                    self._capture(ent)
             if callback is not None and i % callback_steps == 0:                                  # :429
                 callback(i, self.scheduler.timesteps[i].item(), hip.nhwc_to_nchw(ent["latents"]))
         if kwargs.get("return_latents", False):
