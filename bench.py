@@ -26,7 +26,11 @@ Extra objects in the JSON line:
                TFLOP/s and share of GPU time from a HIP-event-bracketed eager pass (one UNet forward + one VAE
                decode of the same batch) run outside the timed region.
   attention    the UNet's 64x64-level self-attention: algorithmic / issued TFLOP/s (live) + PMC MFMA-busy share (committed profile)
-  frames_per_sec_incl_png / walk_60_frames   the literal BASELINE config 2 (60 frames) through walk(), PNG files included
+  frames_per_sec_incl_png / walk_60_frames   the literal BASELINE config 2 (60 frames) through walk(), PNG files included:
+               `frames_per_sec_incl_png` is the WARM walk (step graph already captured - what PNG encode + write cost), the first
+               walk at that batch size is `walk_60_frames` with `cold_start_s` = what the first call paid on top
+  other_configs.batch_sweep   the reference's own operating points: frames per call 1 (walk's default batch_size, :571), 4, 16
+               (tests/test_pipeline.py:66; examples use 12) and 60 - first call (cold) and steady state, 50 steps each
   cpu_baseline the CPU oracle (PyTorch eager fp32 restatement of the reference path) timed on this host's cores
                on a bounded sample - 1 CFG UNet forward (2 samples) + 1 VAE decode at full size - and
                extrapolated to 50 steps.
@@ -327,19 +331,45 @@ def kernel_pass(pipe, embeds, noise, size, steps):
     return out
 
 
+def csrc_fingerprint() -> str:
+    """sha256 over the kernel sources + the C header, in name order: what a committed profile was collected FROM.  (The GPU box has
+    no .git; the content hash needs none.)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted((ROOT / "stable_diffusion_videos_amd" / "csrc").glob("*.h*")) + [ROOT / "include" / "sdv_hip.h"]
+    for f in files:
+        h.update(f.name.encode() + b"\0" + f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def profile_fingerprint(path: Path) -> str:
+    """The `# csrc=<fingerprint>` comment tools/pmc_summary.py / tools/rocpd_stats.py put at the top of a committed profile."""
+    try:
+        first = open(path).readline()
+    except OSError:
+        return ""
+    return first.split("csrc=", 1)[1].split()[0] if first.startswith("#") and "csrc=" in first else ""
+
+
 def pmc_profile(batch):
     """Counters of the committed rocprofv3 --pmc passes over one UNet forward at this bench's batch
-    (profiles/round2_pmc_unet_b<batch>.csv, made by tools/pmc_summary.py from `rocprofv3 --pmc ... tools/unet_once.py <batch>`;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns {kernel: {counter: mean per launch}} or {}
-    when there is no profile for this batch size."""
-    path = next((p for p in (ROOT / "profiles" / f"round4_pmc_unet_b{batch}.csv", ROOT / "profiles" / f"round3_pmc_unet_b{batch}.csv",
-                             ROOT / "profiles" / f"round2_pmc_unet_b{batch}.csv") if p.exists()), None)
-    if path is None:
+    (profiles/round5_pmc_unet_b<batch>.csv, made by tools/pmc_summary.py from `rocprofv3 --pmc ... tools/unet_once.py <batch>`;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns {kernel: {counter: mean per launch}} - or {} when
+    there is no profile for this batch size OR the profile was collected from other kernel sources than this tree's
+    (`# csrc=` fingerprint in its first line != csrc_fingerprint()): a replayed number must describe the code that ships."""
+    path = ROOT / "profiles" / f"round5_pmc_unet_b{batch}.csv"
+    pmc_profile.stale = None
+    if not path.exists():
+        return {}
+    fp = profile_fingerprint(path)
+    if fp != csrc_fingerprint():
+        pmc_profile.stale = (f"profiles/{path.name} was collected from kernel sources {fp or '(unrecorded)'}, this tree is "
+                             f"{csrc_fingerprint()}: not replayed")
         return {}
     pmc_profile.source = f"profiles/{path.name}"
     import csv
     acc = {}
-    for r in csv.DictReader(open(path)):
+    for r in csv.DictReader(ln for ln in open(path) if not ln.startswith("#")):
         a = acc.setdefault((r["kernel"], r["counter"]), [0.0, 0])
         a[0] += float(r["mean"]) * int(r["dispatches"])
         a[1] += int(r["dispatches"])
@@ -365,7 +395,58 @@ def dominant_kernel_traffic(pmc):
     return {"kernel": " + ".join(k for k, _ in ks), "launches_in_profile": n, "fetch_bytes": round(fetch * 2 * 1024),
             "write_bytes": round(write * 1024),
             "source": f"{getattr(pmc_profile, 'source', 'profiles/')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                      "COMMITTED profile of the same forward, not collected in this run)"}
+                      f"COMMITTED profile of the same forward from the same kernel sources - fingerprint {csrc_fingerprint()} - not "
+                      "collected in this run)"}
+
+
+def rocprof_conv_average(batch):
+    """Average launch duration of the dominant kernel (both bf16 variants of the 256 x 320 conv) in the committed
+    `rocprofv3 --kernel-trace --stats` summary of this bench command - only when that summary was collected from this tree's
+    kernel sources - and the algorithmic TFLOP/s it implies, next to the live HIP-event figure."""
+    path = ROOT / "profiles" / f"round5_bench_b{batch}_kernel_stats.csv"
+    if not path.exists() or profile_fingerprint(path) != csrc_fingerprint():
+        return None
+    import csv
+    calls = ns = 0
+    for r in csv.DictReader(ln for ln in open(path) if not ln.startswith("#")):
+        name = r.get("Name", "")
+        if "igemm_kernel<4, 2, 2, 5, 64, true, 2, " in name and name.split("igemm_kernel<4, 2, 2, 5, 64, true, 2, ")[1][0] in "04":
+            calls += int(r["Calls"])
+            ns += float(r["TotalDurationNs"])
+    if not calls:
+        return None
+    avg_us = ns / calls / 1e3
+    # conv bucket of one forward: 200.0 GMAC per sample (SURVEY.md 8a table 2: every conv3x3 incl. down / up) x 2 x 2B samples over 51 launches
+    tf = 200.0e9 * 2 * 2 * batch / 51 / (avg_us * 1e-6) / 1e12
+    return {"avg_launch_us": round(avg_us, 2), "launches": calls, "algorithmic_tflops": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "source": f"profiles/{path.name} (rocprofv3 --kernel-trace --stats of `bench.py --steps 1` on these kernel sources, eager launches)"}
+
+
+def batch_sweep(pipe, size, inference_steps, sizes=(1, 4, 16, 60)):
+    """The reference's own operating points on this GPU (SURVEY.md 8d asks for the sweep; walk()'s default batch_size is 1 -
+    stable_diffusion_pipeline.py:571 -, its test uses 16 - tests/test_pipeline.py:66 -, its example 12): per batch size the FIRST
+    call (buffers + first eager step + graph capture inside the clock) and the steady state (best of two further calls)."""
+    h = size // 8
+    out = {}
+    for B in sizes:
+        T = np.linspace(0.0, 1.0, 3 * B)
+        gen = pipe.generate_inputs("a cat", "a dog", 42, 1337, (1, 4, h, h), T, B)
+        secs = []
+        for _ in range(3):
+            _, e, n = next(gen)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe(latents=n, text_embeddings=e, height=size, width=size, num_inference_steps=inference_steps, guidance_scale=7.5, eta=0.0,
+                 output_type="numpy_u8")
+            torch.cuda.synchronize()
+            secs.append(time.perf_counter() - t0)
+        warm = min(secs[1:])
+        row = {"frames_per_call": B, "frames_per_sec": round(B / warm, 4), "first_call_frames_per_sec": round(B / secs[0], 4),
+               "seconds_per_call": round(warm, 4), "first_call_seconds": round(secs[0], 4)}
+        if FLOP_PER_FRAME.get("sd14") and inference_steps == 50 and size == 512:
+            row["frac_of_mfma_peak"] = round(B / warm * FLOP_PER_FRAME["sd14"] / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        out[str(B)] = row
+    return out
 
 
 def attention_object(shapes, pmc):
@@ -379,14 +460,17 @@ def attention_object(shapes, pmc):
     out = {"shape": {k: row[k] for k in ("B", "H", "Lq", "Lk", "dh")}, "algorithmic_tflops": alg,
            # the kernel pads dh 40 -> 48 for Q.K^T and -> 64 rows for P.V: (48 + 64) / (40 + 40) of the algorithmic MFMA work
            "issued_tflops": round(alg * 1.4, 1), "frac_of_mfma_peak_algorithmic": round(alg / MFMA_PEAK_TFLOPS, 3),
-           "frac_of_mfma_peak_issued": round(alg * 1.4 / MFMA_PEAK_TFLOPS, 3)}
+           "frac_of_mfma_peak_issued": round(alg * 1.4 / MFMA_PEAK_TFLOPS, 3),
+           "north_star_metric": "mfma_busy_useful (PMC matrix-pipe busy share / 1.4: the padding MFMAs of dh 40 -> 48 / 64 are NOT "
+                                "counted as utilisation); BASELINE.json asks for >= 0.50"}
     for k, c in pmc.items():
         if k.startswith("attention_kernel<40, 2") and "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             # busy cycles summed over 1024 SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs
             out["mfma_busy_pmc"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
             # useful share of the matrix pipe: the busy counter also counts the dh 40 -> 48 / 64 padding MFMAs (x1.4)
             out["mfma_busy_useful"] = round(out["mfma_busy_pmc"] / 1.4, 3)
-            out["mfma_busy_source"] = f"{getattr(pmc_profile, 'source', 'profiles/')} (committed profile, not collected in this run)"
+            out["mfma_busy_source"] = (f"{getattr(pmc_profile, 'source', 'profiles/')} (committed profile of THESE kernel sources - "
+                                       f"fingerprint {csrc_fingerprint()} - not collected in this run)")
     return out
 
 
@@ -558,6 +642,11 @@ def main():
                     result["roofline"]["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
                     result["roofline"]["traffic_source"] = tr["source"]
                     result["roofline"]["dominant_kernel"]["traffic"] = tr
+                elif getattr(pmc_profile, "stale", None):
+                    result["roofline"]["traffic_source"] = pmc_profile.stale
+                rp = rocprof_conv_average(B)
+                if rp:
+                    result["roofline"]["dominant_kernel"]["rocprof"] = rp
             att = attention_object(shapes, pmc)
             if att:
                 result["attention"] = att
@@ -573,10 +662,9 @@ def main():
                           batch_size=60, height=size, width=size, num_inference_steps=args.inference_steps, make_video=False)
                 dt = time.perf_counter() - t1
                 n_png = len(list(Path(tmp).rglob("frame*.png")))
-                result["frames_per_sec_incl_png"] = round(n_png / dt, 4)
-                result["walk_60_frames"] = {"frames": n_png, "seconds": round(dt, 3), "batch_size": 60,
-                                            "includes": "COLD: graph warm-up + capture for the 60-frame batch, text encoder, "
-                                                        "interpolation, denoise, VAE, D2H, PNG encode + write"}
+                result["walk_60_frames"] = {"frames": n_png, "seconds": round(dt, 3), "batch_size": 60, "frames_per_sec": round(n_png / dt, 4),
+                                            "includes": "COLD (first call at this batch size): buffers, first eager step + graph capture, "
+                                                        "text encoder, interpolation, denoise, VAE, D2H, PNG encode + write"}
                 # the same walk a second time: the 60-frame step graph is cached, the number a long-running service sees
                 t1 = time.perf_counter()
                 pipe.walk(["a cat", "a dog"], seeds=[42, 1337], num_interpolation_steps=60, output_dir=tmp, name="w2",
@@ -585,6 +673,9 @@ def main():
                 n2 = len(list((Path(tmp) / "w2").rglob("frame*.png")))
                 result["walk_60_frames_warm"] = {"frames": n2, "seconds": round(dt2, 3), "frames_per_sec": round(n2 / dt2, 4),
                                                  "batch_size": 60, "includes": "as walk_60_frames, step graph already captured"}
+                # the PNG-inclusive rate is the WARM walk (the cold one measures the first call's set-up, reported on its own)
+                result["frames_per_sec_incl_png"] = round(n2 / dt2, 4)
+                result["walk_60_frames"]["cold_start_s"] = round(dt - dt2, 3)
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         if args.config == 2 and not args.no_parity_check:
@@ -608,11 +699,15 @@ def main():
             # BASELINE configs 4 and 5 on this GPU, short passes with their own warm-up (the headline `value` above stays
             # config 2 in bf16).  The bf16 pipeline's graphs and buffers go first.
             import gc
-            pipe._graphs.clear()
+            oc = {}
+            try:
+                oc["batch_sweep"] = batch_sweep(pipe, size, args.inference_steps)
+            except Exception as exc:  # the headline line must still be printed
+                oc["batch_sweep"] = {"error": repr(exc)}
+            pipe._drop_graphs()
             del pipe, gen
             gc.collect()
             torch.cuda.empty_cache()
-            oc = {}
             for key, kw in (("sd21_768", dict(arch="sd21", size=768, B=32, dtype="bf16")),
                             ("fp8_mx", dict(arch="sd14", size=512, B=B, dtype="fp8"))):
                 try:

@@ -1146,7 +1146,15 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
     constexpr bool PERSIST = WM * WN == 8;                             // (see the kernel)
     constexpr int SLABS = 2 * WM * WN * 32 * 144;                      // the epilogue's staging slabs (alias ONE K-slab buffer)
     constexpr int SLOT = PERSIST && SLABS > TILE_BYTES ? SLABS : TILE_BYTES;
-    constexpr int LDS = NST * SLOT + 3 * BN * 4 + WM * WN * 256;       // K-slab buffers + column vectors + FEAT 3's row-stat accumulators
+    // K-slab buffers + column vectors + FEAT 3's row-stat accumulators.  + 48 KiB that nothing uses for the LayerNorm-fold / row-statistics
+    // variants of the 4-wave 128 x 128 tile: that tile normally runs TWO workgroups per CU (68 KiB each), and its fold variants are
+    // not safe in company - round 4's column-side fold raced against its own second workgroup (11 of 11 repeated launches differed),
+    // and the row-side GEGLU consumer gave 12 of 300 forwards a different result while ANOTHER PROCESS kept the GPU busy (two ranks on
+    // one GPU: tools/contention_probe.py, profiles/round5_contention_probe.txt); alone on its CU - this padding, or the 8-wave tiles,
+    // which own their CU's LDS anyway - both were clean in 300 of 300.  What exactly two co-resident workgroups do to each other
+    // there is NOT understood (idle slots, full drains and full barriers around the LDS vector reads changed nothing: DESIGN.md);
+    // one workgroup per CU is the measured cure, and it costs 0 - 2 % at 1 - 4 frames per call, nothing above.
+    constexpr int LDS = NST * SLOT + 3 * BN * 4 + WM * WN * 256 + ((WM * WN == 4 && (FEAT == 1 || FEAT == 3)) ? 48 * 1024 : 0);
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static unsigned long long attr_set = 0;   // one bit per device: the attribute belongs to the device's copy of the function
     const unsigned long long dev_bit = 1ull << current_device();

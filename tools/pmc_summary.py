@@ -23,7 +23,11 @@ for path in sys.argv[2:]:
             continue
         key = (k, r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["LDS_Block_Size"], r["Counter_Name"])
         agg.setdefault(key, []).append(float(r["Counter_Value"]))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (csrc_fingerprint: which kernel sources these counters were collected from - bench.py refuses to replay others)
+
 with open(sys.argv[1], "w") as f:
+    f.write(f"# csrc={bench.csrc_fingerprint()} rocprofv3 --pmc passes of tools/unet_once.py, summarised by tools/pmc_summary.py\n")
     w = csv.writer(f)
     w.writerow(["kernel", "grid", "workgroup", "vgpr", "lds_bytes", "counter", "dispatches", "mean", "min", "max"])
     for key, v in agg.items():
