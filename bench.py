@@ -172,13 +172,17 @@ def config3_plan(world: int, rank: int, B: int, counts=None):
 
 
 def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
-    """Self-check of the benchmarked configuration, OUTSIDE the clock: four frames of the last timed batch are generated again
-    in a 4-frame call (eager, so nothing of the big batch's captured graph is reused) and compared with what the big batch
-    returned - (a) with the tile selection the library makes for 8 samples, (b) with every igemm forced onto the 256 x 320 tile
-    the big batch runs.  (b) must be BIT-IDENTICAL: every output element sees the same sequence of MFMA k-steps whatever the
-    batch, the GroupNorm statistics are split by image size only, attention is per (sample, head).  (a) is a second, independent
-    realisation of the bf16 roundings (other tiles -> other partial-sum groupings of the LayerNorm row statistics -> a flipped
-    rounding early on, tests/test_bench_config_gpu.py): it must sit where two bf16 realisations sit, PSNR >= 37 dB."""
+    """Self-check of the benchmarked configuration, OUTSIDE the clock: four frames of the last timed batch are generated again in
+    a 4-frame call and compared with what the timed batch returned -
+    (a) with the tile selection the library makes for 8 samples.  When the timed batch WAS a 4-frame batch this is the same
+        computation and must be BIT-IDENTICAL; otherwise it is a second, independent realisation of the bf16 roundings (other
+        tiles -> other partial-sum groupings of the LayerNorm row statistics -> a flipped rounding early on,
+        tests/test_bench_config_gpu.py) and must sit where two bf16 realisations sit, PSNR >= 37 dB;
+    (b) with every igemm forced onto the 256 x 320 tile (hip.FORCE_TILE = 6) - only for chip-filling timed batches (>= 64 frames),
+        which run that tile themselves: then every output element sees the same sequence of MFMA k-steps whatever the batch, the
+        GroupNorm statistics are split by image size only, attention is per (sample, head), and the frames must be BIT-IDENTICAL.
+        (For a small timed batch the comparison would pit the cost model's small tiles against a forced big one - two realisations.)
+    Both recomputations run eagerly (no step graph is captured for them), so (b)'s launches really are the forced tile's."""
     from stable_diffusion_videos_amd import hip
     B = embeds.shape[0]
     idx = sorted({0, max(B // 2 - 1, 0), B // 2, B - 1})
@@ -186,21 +190,28 @@ def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
     kw = dict(latents=noise[sel].contiguous(), text_embeddings=embeds[sel].contiguous(), height=size, width=size,
               num_inference_steps=inference_steps, guidance_scale=7.5, eta=0.0, output_type="numpy_u8")
     graphs, prev_tile = pipe.use_graphs, hip.FORCE_TILE
-    out = {"frames": idx, "vs": f"the same frames recomputed in a {len(idx)}-frame call (eager)", "min_psnr_db": 37.0}
+    same_batch, forced = len(idx) == B, B >= 64
+    out = {"frames": idx, "vs": f"the same frames recomputed in a {len(idx)}-frame call", "min_psnr_db": 37.0}
+    b = None
     try:
-        pipe.use_graphs = False
+        pipe.use_graphs = False          # (a new batch size runs eagerly: (b) must not find a step captured with (a)'s tiles)
         a = pipe(**kw)["images"]
-        hip.FORCE_TILE = 6
-        b = pipe(**kw)["images"]
+        if forced:
+            hip.FORCE_TILE = 6
+            b = pipe(**kw)["images"]
     finally:
         pipe.use_graphs, hip.FORCE_TILE = graphs, prev_tile
     ref = frames_u8[idx].astype(np.int32)
-    da, db = np.abs(a.astype(np.int32) - ref), np.abs(b.astype(np.int32) - ref)
+    da = np.abs(a.astype(np.int32) - ref)
     mse = float((da.astype(np.float64) ** 2).mean())
-    out.update(max_abs_u8_same_tiles=int(db.max()), max_abs_u8=int(da.max()), mean_abs_u8=round(float(da.mean()), 4),
+    out.update(max_abs_u8=int(da.max()), mean_abs_u8=round(float(da.mean()), 4),
                psnr_db=round(10.0 * float(np.log10(255.0 ** 2 / max(mse, 1e-12))), 2),
                frames_differ=bool(np.abs(ref[0] - ref[-1]).mean() > 0.5))
-    out["ok"] = bool(out["max_abs_u8_same_tiles"] == 0 and out["psnr_db"] >= out["min_psnr_db"] and out["frames_differ"])
+    ok = out["frames_differ"] and (out["max_abs_u8"] == 0 if same_batch else out["psnr_db"] >= out["min_psnr_db"])
+    if b is not None:
+        out["max_abs_u8_same_tiles"] = int(np.abs(b.astype(np.int32) - ref).max())
+        ok = ok and out["max_abs_u8_same_tiles"] == 0
+    out["ok"] = bool(ok)
     return out
 
 

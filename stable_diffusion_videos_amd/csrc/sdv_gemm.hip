@@ -766,6 +766,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
                 // 4, 3 (the items: rows r, r+16 first, then r+8), then 2, 1, 0 (the lanes) - so the statistics of a tensor do not
                 // depend on the tile the cost model picked for its producer (batch size, CFG-shared prefix ...).
                 auto gn_reduce_store = [&](int pi, const u32x4_t* pk) {
+                    // The file is built with -ffast-math: without these two lines every template instance is free to re-associate the
+                    // sums below its own way, and the "same tree whatever the tile" of the comment above held by luck of codegen - the
+                    // phase-form up-conv's statistics differed in the last fp32 bit in 0.3 % of the entries between the 256 x 320 tile and
+                    // a 4-wave tile (tools/vae_tile_probe.py), enough to flip a uint8 of a frame decoded from large latents.
+#pragma clang fp reassociate(off)
+#pragma clang fp contract(off)
                     const int cpo = p_oc(pi) >> 3;                                  // lanes per row of the pass: 8 or 4
                     float cs[8], cq[8];
 #pragma unroll
