@@ -335,7 +335,8 @@ class StableDiffusionWalkPipeline:
                 self._sched_cache.pop(gone)
                 # captured steps bake in the pointers of that schedule's coefficient / time-embedding tables
                 for gk in [k for k in self._graphs if k[0] == gone]:
-                    self._graphs.pop(gk)["graph"] = None
+                    dead = self._graphs.pop(gk)
+                    dead["graph"] = dead["one_step"] = None
             coefs = (self.scheduler.coefficient_table(eta) if ddim else self.scheduler.fused_table()).to(self.device)
             self.unet.prepare_timesteps(ts)
             tables = [r.bias_table for r in self.unet.res]
@@ -364,7 +365,7 @@ class StableDiffusionWalkPipeline:
         cross-attention buffers it held raw pointers into."""
         sizes = {k[1] for k in self._graphs}
         for ent in self._graphs.values():
-            ent["graph"] = None
+            ent["graph"] = ent["one_step"] = None        # (the closure holds the entry: break the cycle, the buffers go now)
         self._graphs.clear()
         for nimg in sizes:
             self.unet.release(nimg)
@@ -434,7 +435,7 @@ class StableDiffusionWalkPipeline:
         while len(self._graphs) >= self.max_cached_graphs:     # every captured step owns a multi-GB private pool
             old_key = next(iter(self._graphs))
             ent = self._graphs.pop(old_key)
-            ent["graph"] = None
+            ent["graph"] = ent["one_step"] = None
             del ent
             # the cross-attention K / V^T buffers and V^T workspaces are kept per batch size because captured graphs hold raw
             # pointers into them: once no cached graph runs at that batch size any more they go too (a resumed walk with many
@@ -489,12 +490,24 @@ class StableDiffusionWalkPipeline:
         mode = "thread_local" if parallel.world()[1] > 1 else "global"
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            g.capture_begin(pool=self._graph_pool, capture_error_mode=mode)
-            try:
-                ent["one_step"]()
-            finally:
-                g.capture_end()
+        # No garbage collection while the stream captures: an unreachable step graph of an earlier call (its entry holds a closure
+        # that holds the entry - a cycle only the collector frees) would be destroyed in the middle of the capture, and destroying
+        # a graph / returning its blocks is not a capturable call (seen as a crash inside the first captured launch when this ran
+        # late in a long test session; ``torch.cuda.graph`` runs a full ``gc.collect()`` up front for the same reason - switching
+        # the collector off for the ~10 ms of the capture costs nothing).
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.stream(side):
+                g.capture_begin(pool=self._graph_pool, capture_error_mode=mode)
+                try:
+                    ent["one_step"]()
+                finally:
+                    g.capture_end()
+        finally:
+            if gc_was_on:
+                gc.enable()
         torch.cuda.current_stream().wait_stream(side)
         ent["graph"] = g
         ent["capture_pending"] = False
