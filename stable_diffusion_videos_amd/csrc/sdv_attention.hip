@@ -449,7 +449,20 @@ __global__ __launch_bounds__(NW * 64, (DH == 64 && VRM && !RES) ? 4 : 1) void at
 #pragma unroll
                     for (int e = 0; e < 16; ++e) o[qt][dt][e] *= alpha;
             };
-            auto vfrag = [&](int dt, int ju) __attribute__((always_inline)) { return vfrag_at(0, dt, ju); };
+            // V fragments: with a row-major V every fragment costs TWO transposing reads, and the loop is instruction-issue bound -
+            // read each fragment ONCE per key tile and use it for both query tiles (32 more live registers: 198 -> ~230, still two
+            // waves per SIMD) instead of once per query tile (tools/attn_vrm_ab.py: the per-query-tile reads cost the 64 x 64 level 7 %)
+            bf16x8_t vfr[VRM ? DVT : 1][VRM ? 4 : 1];
+            if constexpr (VRM) {
+#pragma unroll
+                for (int ju = 0; ju < 4; ++ju)
+#pragma unroll
+                    for (int dt = 0; dt < DVT; ++dt) vfr[dt][ju] = vfrag_at(0, dt, ju);
+            }
+            auto vfrag = [&](int dt, int ju) __attribute__((always_inline)) {
+                if constexpr (VRM) return vfr[dt][ju];
+                else return vfrag_at(0, dt, ju);
+            };
             auto exp_quarter = [&](const f32x16_t& a, int u) {                  // 8 scores -> one B fragment
                 u32x4_t pr;
 #pragma unroll
