@@ -128,10 +128,19 @@ typedef struct sdv_gemm_args {
      * sdv_groupnorm_finalize turns the blocks of an image (and the channels of a group) into sdv_groupnorm_apply's partials. */
     float* gn_out;
     int32_t gn_ld;
+    /* SPLIT-K for the small-batch regime (walk()'s default batch_size is 1, stable_diffusion_pipeline.py:571; its test uses 16): with
+     * few samples the low-resolution convs / GEMMs have M = 128 ... 2048 rows against K up to 23 040 - a handful of tiles on 256 CUs.
+     * split_k > 1 on entry (with out_mode 0 and out_f32 = a workspace of [split_k][M][N] floats): the launch MAY give every output tile
+     * to up to split_k workgroups, each taking a contiguous range of K slabs and leaving its fp32 partial sums in the workspace; a
+     * second pass adds them in split order (deterministic), applies alpha / bias / residual and rounds once.  Plain launches only
+     * (epi 0, no fold / statistics / fp8 / typed output / batch / phase form), 4-wave tiles only (1 - 3), >= 1024 K values per split.
+     * sdv_gemm_split_k(args) tells how many splits a launch would take (1 = none), so the caller can size the workspace. */
+    int32_t split_k;
 } sdv_gemm_args;
 
 int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream);
 int sdv_gemm_stats_slots(const sdv_gemm_args* args);
+int sdv_gemm_split_k(const sdv_gemm_args* args);
 
 /* The 8-wave tiles (6-9) run as PERSISTENT workgroups - one per CU, each walking tiles b, b + grid, ... with the next tile's
  * first K slab prefetched behind the current tile's epilogue.  sdv_gemm_set_persistent(0) falls back to one workgroup per

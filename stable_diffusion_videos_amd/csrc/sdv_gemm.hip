@@ -106,6 +106,13 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     const int nblk = tiles_m * tiles_n;
     const int total = nblk * (p.batch > 0 ? p.batch : 1);
     const int K = p.K;
+    // SPLIT-K (sdv_hip.h "split_k"; the plain variants of the 4-wave tiles only, so that no 8-wave kernel sees a line of it): with few
+    // frames per call the low-resolution layers have M = 128 ... 2048 rows against K = 11 520 ... 23 040 - a handful of tiles on 256
+    // CUs, each walking hundreds of K slabs.  S workgroups per tile then take S contiguous K-slab ranges (blockIdx = split * tiles +
+    // tile) and leave their fp32 accumulators in a workspace [S][M][N]; splitk_reduce_kernel adds the S partials in split order
+    // (deterministic), applies alpha / bias / residual and rounds once.
+    constexpr bool SPLITK = NWV == 4 && FEAT == 0;
+    int ks_ = 0, seek_r = 0;   // this workgroup's split; K slabs to skip inside the first segment it stages
 
     // ---- operand addressing: buffer descriptors + 32-bit lane offsets + scalar K offset -----------------
     constexpr unsigned kOOB = 0x80000000u;
@@ -141,6 +148,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         {
         bz = vb / nblk;           // batch index (mode 4: the phase)
         const int lb = vb - bz * nblk;
+        if constexpr (SPLITK) {
+            if (p.split_k > 1) {      // (not batched: the block index above the tiles is the split)
+                ks_ = bz;
+                bz = 0;
+            }
+        }
         // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs; remap
         // (bijectively) so that each XCD - each private L2 - works on one contiguous run of tiles: neighbouring
         // M tiles of a conv share their halo rows, and all tiles of a run share the same W panel.
@@ -218,6 +231,19 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         kx = 0;
         kwb = 0;
         halves_left = (K / BK) * (CONV ? (p.mode == 4 ? 4 : 9) : 1);
+        if constexpr (SPLITK) {
+            if (p.split_k > 1) {
+                // first K slab of this split: which (tap, source) segment it lies in and how far into it
+                const int all = (K / BK) * (CONV ? 9 : 1);
+                const int k0 = (int)((long long)ks_ * all / p.split_k);
+                const int seg1 = p.C1 / BK, per_tap = K / BK;
+                tap = k0 / per_tap;
+                int r = k0 - tap * per_tap;
+                srcsel = r >= seg1 ? 1 : 0;
+                seek_r = srcsel ? r - seg1 : r;
+                kwb = k0 * ROWB;
+            }
+        }
     };
 
     // The K loop walks segments = (tap, source) pairs; inside a segment only the scalar offset advances.
@@ -262,7 +288,14 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         // past the descriptor's range (the range check answers with zeros, nothing is fetched), no bookkeeping advances
         const bool dead = MX && hf == 1 && halves_left == 0;
         const unsigned dmask = dead ? kOOB : 0u;
-        if (!dead && seg_left == 0) new_segment();
+        if (!dead && seg_left == 0) {
+            new_segment();
+            if constexpr (SPLITK) {          // (a split that starts inside a segment: seek_r is 0 everywhere else)
+                kx += seek_r * ROWB;
+                seg_left -= seek_r;
+                seek_r = 0;
+            }
+        }
         const __amdgpu_buffer_rsrc_t rs_x = srcsel ? rs_x2 : rs_x1;
         if (issue) {
 #pragma unroll
@@ -432,7 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     };
 
     const int ntaps = CONV ? (p.mode == 4 ? 4 : 9) : 1;
-    const int nkt = MX ? ((K / BK) * ntaps + 1) / 2 : (K / BK) * ntaps;   // (MX: two 64-wide K images per slab)
+    int nkt = MX ? ((K / BK) * ntaps + 1) / 2 : (K / BK) * ntaps;   // (MX: two 64-wide K images per slab; split-K: this split's share, below)
     // tile walk state: `vb` = the tile being computed, `slot0` = the LDS slot its first K slab is in, `landed` = that slab
     // was fetched (and waited for) during the tile before
     int vb = blockIdx.x;
@@ -477,6 +510,25 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
     auto epilogue = [&]() {
     const int m0 = e_m0, n0 = e_n0, bn = e_bn;
     const long long bz = e_bzi;
+    if constexpr (SPLITK) {
+        if (p.split_k > 1) {          // this split's partial sums, unscaled fp32, straight from the accumulators (N % 4 == 0: host)
+            float* __restrict__ ws = p.out_f32 + (long long)ks_ * p.M * p.N;
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    const int m = m0 + wm * TM * 32 + mt * 32 + l31;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int nb = n0 + wn * TN * 32 + nt * 32 + 8 * g4 + 4 * lhi;
+                        if (m < p.M && nb < p.N)
+                            *(float4*)(ws + (long long)m * p.N + nb) = make_float4(acc[nt][mt][4 * g4], acc[nt][mt][4 * g4 + 1],
+                                                                                  acc[nt][mt][4 * g4 + 2], acc[nt][mt][4 * g4 + 3]);
+                    }
+                }
+            return;
+        }
+    }
     const float alpha = p.alpha;
     const int acols = p.alpha_cols > 0 ? p.alpha_cols : 0x7fffffff;
     const float* bias = p.bias;
@@ -1109,6 +1161,12 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         e_bn = a_bn;
         e_bzi = a_bz;
         has_next = PERSIST && vb + (int)gridDim.x < total;
+        if constexpr (SPLITK) {
+            if (p.split_k > 1) {
+                const int all = (K / BK) * ntaps;
+                nkt = (int)((long long)(ks_ + 1) * all / p.split_k) - (int)((long long)ks_ * all / p.split_k);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -1121,6 +1179,80 @@ __global__ __launch_bounds__(WM * WN * 64, (((BK == 32 && NST == 2) ? 2 : 1) * W
         vb += (int)gridDim.x;
         slot0 = (slot0 + nkt) & 1;
         landed = true;
+    }
+}
+
+// Second pass of a split-K launch: C[m][n] = bf16( alpha * sum_s ws[s][m][n] + bias (+ R[m][n]) ), the S partials added in split order.
+// GN: a workgroup owns a 32-row x 64-column block of the result and also emits the block's per-column (sum, sumsq) of the STORED bf16
+// values into gn_out (sdv_hip.h "gn_out" layout) - the consumer's GroupNorm then needs no statistics pass of its own, as after an
+// unsplit launch (rows summed in row order: deterministic; not the unsplit epilogue's tree, but a split result is another fp32
+// summation order anyway).
+template <bool GN>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N, float alpha,
+                                                            const float* __restrict__ bias, int bias_mode, const int32_t* step_ptr,
+                                                            int bias_step_stride, const uint16_t* __restrict__ R, int ldr,
+                                                            uint16_t* __restrict__ C, int ldc, float* __restrict__ gn_out, int gn_ld) {
+    if (bias && step_ptr) bias += (long long)(*step_ptr) * bias_step_stride;
+    auto one = [&](int m, int n, float* kept) {      // one float4 of the result: reduce, finish, round, store
+        float4 a = *(const float4*)(ws + (long long)m * N + n);
+        for (int s = 1; s < S; ++s) {
+            const float4 b = *(const float4*)(ws + ((long long)s * M + m) * N + n);
+            a.x += b.x;
+            a.y += b.y;
+            a.z += b.z;
+            a.w += b.w;
+        }
+        float v[4] = {a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha};
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bias_mode == 2 ? bias[m] : bias[n + e];
+        }
+        if (R) {
+            const uint2 r = *(const uint2*)(R + (long long)m * ldr + n);
+            v[0] += __uint_as_float(r.x << 16);
+            v[1] += __uint_as_float(r.x & 0xffff0000u);
+            v[2] += __uint_as_float(r.y << 16);
+            v[3] += __uint_as_float(r.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *(uint2*)(C + (long long)m * ldc + n) = o;
+        if (kept) {
+            kept[0] = __uint_as_float(o.x << 16);
+            kept[1] = __uint_as_float(o.x & 0xffff0000u);
+            kept[2] = __uint_as_float(o.y << 16);
+            kept[3] = __uint_as_float(o.y & 0xffff0000u);
+        }
+    };
+    if constexpr (!GN) {
+        const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+        const int nq = N >> 2;
+        if (q >= (long long)M * nq) return;
+        const int m = (int)(q / nq);
+        one(m, (int)(q - (long long)m * nq) * 4, nullptr);
+    } else {
+        __shared__ float blk[32][65];
+        const int r = threadIdx.x >> 3, cg = threadIdx.x & 7;
+        const int m = blockIdx.x * 32 + r, n0 = blockIdx.y * 64;     // (M % 32 == 0 whenever gn_out is set)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = h * 32 + cg * 4;
+            float kept[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n0 + c < N) one(m, n0 + c, kept);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) blk[r][c + e] = kept[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int c = threadIdx.x & 63, st = threadIdx.x >> 6;
+            float acc = 0.f;
+            for (int rr = 0; rr < 32; ++rr) {
+                const float x = blk[rr][c];
+                acc = st ? __builtin_fmaf(x, x, acc) : acc + x;
+            }
+            if (n0 + c < N) gn_out[((long long)blockIdx.x * 2 + st) * gn_ld + n0 + c] = acc;
+        }
     }
 }
 
@@ -1170,8 +1302,9 @@ int launch_igemm_t(const sdv_gemm_args& a, hipStream_t stream) {
         attr_set |= dev_bit;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    const long long total = (long long)tiles_m * tiles_n * (a.batch > 0 ? a.batch : 1);
+    const long long total = (long long)tiles_m * tiles_n * (a.split_k > 1 ? a.split_k : (a.batch > 0 ? a.batch : 1));
     SDV_REQUIRE(total < 0x7fffffffLL, "sdv_gemm_bf16: too many tiles");
+    SDV_REQUIRE(a.split_k <= 1 || (WM * WN == 4 && FEAT == 0), "sdv_gemm_bf16: split-K exists in the plain 4-wave tiles only");
     const int cus = g_grid_limit > 0 && g_grid_limit < num_cus() ? g_grid_limit : num_cus();
     const bool walk = PERSIST && g_persistent && total > cus;
     dim3 grid((unsigned)(walk ? cus : total), 1, 1);
@@ -1213,13 +1346,17 @@ int launch_igemm(const sdv_gemm_args& a, hipStream_t stream) {
 
 }  // namespace
 
-static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only);
+static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, int plan);   // plan: 0 launch, 1 -> stats slots, 2 -> split-K factor
 
-extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) { return sdv_gemm_impl(args, stream, false); }
+extern "C" int sdv_gemm_bf16(const sdv_gemm_args* args, void* stream) { return sdv_gemm_impl(args, stream, 0); }
+
+// Split-K factor sdv_gemm_bf16 would use for these arguments if it were given a workspace (>= 2), or 1: the caller sizes the
+// workspace out_f32 as [S][M][N] floats, sets split_k = S and launches.
+extern "C" int sdv_gemm_split_k(const sdv_gemm_args* args) { return sdv_gemm_impl(args, nullptr, 2); }
 
 // Number of (sum, sumsq) slots per output row that sdv_gemm_bf16 would write to `stats_out` for these arguments
 // (= N tiles x wave columns of the tile the launch would pick); the caller sizes stats_out as [batch][M][slots][2] floats.
-extern "C" int sdv_gemm_stats_slots(const sdv_gemm_args* args) { return sdv_gemm_impl(args, nullptr, true); }
+extern "C" int sdv_gemm_stats_slots(const sdv_gemm_args* args) { return sdv_gemm_impl(args, nullptr, 1); }
 
 // 1 (default): the 8-wave tiles run as persistent workgroups (one per CU, walking tiles); 0: one workgroup per tile.  Returns
 // the previous setting.  Results are identical either way; this exists so tools/ can time both on the same box.
@@ -1235,10 +1372,14 @@ extern "C" int sdv_gemm_set_grid_limit(int n) {
     return prev;
 }
 
-static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only) {
+static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, int plan) {
     SDV_REQUIRE(args != nullptr, "sdv_gemm_bf16: null args");
     sdv_gemm_args a = *args;
     SDV_REQUIRE(a.X && a.W && (a.C || a.out_mode), "sdv_gemm_bf16: null operand");
+    // split-K: `split_k` > 1 = the caller holds a workspace out_f32 [split_k][M][N] (out_mode 0) and allows up to that many splits;
+    // plan 2 asks how many this launch would take
+    const int split_cap = plan == 2 ? 8 : ((a.split_k > 1 && a.out_f32 && !a.out_mode) ? (a.split_k < 8 ? a.split_k : 8) : 1);
+    a.split_k = 1;
     SDV_REQUIRE(a.out_mode >= 0 && a.out_mode <= 3, "sdv_gemm_bf16: bad out_mode %d", a.out_mode);
     if (a.out_mode) {
         // out_mode 1 (fp32 output) takes any N and a batch (stride sC, in fp32 elements): the VAE attention's scores leave the
@@ -1327,6 +1468,19 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
     int tile = a.tile;
     const long long nb = a.batch > 0 ? a.batch : 1;
     auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nb; };
+    // Split-K factor of a small-tile launch with `nblocks` output tiles: only plain launches (the second pass applies alpha / bias /
+    // residual - no activation, fold, statistics, typed output, batch or phase form), only when the tiles leave most CUs idle, never
+    // fewer than 16 K slabs (1024 K values) per split, at most what the caller's workspace holds.
+    const long long kslabs = (long long)(a.K / 64) * (a.mode ? 9 : 1);
+    const bool split_ok = split_cap > 1 && !a.fp8 && !a.ln_side && !a.stats_out && !a.out_mode && a.epi == 0 && a.batch <= 1 &&
+                          a.mode != 4 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0);
+    auto splits_for = [&](long long nblocks) -> int {
+        if (!split_ok || nblocks > 128 || kslabs < 32) return 1;
+        long long sk = 256 / nblocks;
+        if (sk > kslabs / 16) sk = kslabs / 16;
+        if (sk > split_cap) sk = split_cap;
+        return sk >= 2 ? (int)sk : 1;
+    };
     if (tile == 0) {
         // Cost model over the compiled tiles, calibrated with tools/tile_sweep.py on MI355X: time ~ workgroups the
         // busiest CU runs x tile area / rate, rate = MFMA throughput per busy CU (TFLOP/s) of that tile's K loop.
@@ -1345,13 +1499,17 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         for (const Cand& c : cands) {
             if (a.epi >= 3 && c.id >= 6) continue;   // extended activations exist in the 4-wave tiles only
             if ((a.ln_side || a.stats_out || a.fp8) && !(c.id == 1 || c.id == 6 || c.id == 7 || c.id == 9)) continue;   // LN fold / fp8 tiles
-            const long long per_cu = (blocks(c.bm, c.bn) + 255) / 256;            // workgroups on the busiest CU
-            const double cost = (double)per_cu * c.bm * c.bn / c.rate;            // padded tiles are counted
+            const int sk = c.id <= 3 ? splits_for(blocks(c.bm, c.bn)) : 1;
+            const long long per_cu = (blocks(c.bm, c.bn) * sk + 255) / 256;       // workgroups on the busiest CU
+            const double cost = (double)per_cu * c.bm * c.bn / c.rate / sk;       // padded tiles are counted
             if (cost < best) {
                 best = cost;
                 tile = c.id;
+                a.split_k = sk;
             }
         }
+    } else if (tile >= 1 && tile <= 3) {
+        a.split_k = splits_for(blocks(tile == 3 ? 64 : 128, tile == 1 ? 128 : 64));
     }
     a.tile = 4;   // the kernel reads `tile` as the raster strip width: 8 x 4 blocks of output tiles per XCD wave (1 / 2 / 4 / 8
                   // measured on the UNet: 120.2 / 118.5 / 118.1 / 118.0 ms per forward, profiles/round2_raster_order.txt)
@@ -1361,9 +1519,11 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
         SDV_REQUIRE(tile >= 1 && tile <= 11 && kBN[tile], "sdv_gemm_bf16: bad tile %d (1-4, 6-11)", tile);
         a.stats_p = ((a.N + kBN[tile] - 1) / kBN[tile]) * kWN[tile];
     }
-    if (plan_only) return a.stats_p;
+    if (plan == 1) return a.stats_p;
+    if (plan == 2) return a.split_k;
     SDV_REQUIRE(!(a.epi >= 3 && tile >= 6 && tile <= 9), "sdv_gemm_bf16: epi %d is not available in the 8-wave tile %d", a.epi, tile);
     SDV_REQUIRE(!(a.epi == 1 && a.R), "sdv_gemm_bf16: GEGLU does not take a residual");
+    auto run_tile = [&]() -> int {
     switch (tile) {
 #ifdef SDV_GEMM_ONLY_TILE6   // (tools: compile the 256 x 320 tile alone for resource / ISA inspection)
         case 6: return launch_igemm<4, 2, 2, 5, 64, 2, true>(a, s);
@@ -1381,5 +1541,18 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, bool plan_only
 #endif
         default: SDV_REQUIRE(false, "sdv_gemm_bf16: bad tile %d", tile);
     }
+    return SDV_OK;
+    };
+    const int rc = run_tile();
+    if (rc != SDV_OK || a.split_k <= 1) return rc;
+    // second pass of a split-K launch (same stream: ordered behind the partial sums)
+    const long long quads = (long long)a.M * (a.N >> 2);
+    if (a.gn_out)     // (the GroupNorm statistics of a split launch come out of the second pass - the first one only holds partial sums)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)(a.M / 32), (unsigned)((a.N + 63) / 64)), dim3(256), 0, s, a.out_f32, a.split_k,
+                           a.M, a.N, a.alpha, a.bias, a.bias_mode, a.step_ptr, a.bias_step_stride, a.R, a.ldr, a.C, a.ldc, a.gn_out, a.gn_ld);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.out_f32, a.split_k, a.M, a.N,
+                           a.alpha, a.bias, a.bias_mode, a.step_ptr, a.bias_step_stride, a.R, a.ldr, a.C, a.ldc, (float*)nullptr, 0);
+    SDV_CHECK_LAUNCH("sdv_gemm_bf16 (split-K reduce)");
     return SDV_OK;
 }

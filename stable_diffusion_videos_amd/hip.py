@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("alpha_cols", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("stats_out", C.c_void_p), ("ln_side", C.c_int32), ("stats_p", C.c_int32),
         ("fp8", C.c_int32), ("out_mode", C.c_int32), ("out_f32", C.c_void_p), ("out_u8", C.c_void_p),
-        ("gn_out", C.c_void_p), ("gn_ld", C.c_int32),
+        ("gn_out", C.c_void_p), ("gn_ld", C.c_int32), ("split_k", C.c_int32),
     ]
 
 
@@ -50,6 +50,7 @@ _SIGNATURES = {
     "sdv_abi_version": (C.c_int, []),
     "sdv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "sdv_gemm_stats_slots": (C.c_int, [C.POINTER(GemmArgs)]),
+    "sdv_gemm_split_k": (C.c_int, [C.POINTER(GemmArgs)]),
     "sdv_gemm_set_persistent": (C.c_int, [C.c_int]),
     "sdv_gemm_set_grid_limit": (C.c_int, [C.c_int]),
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
@@ -200,6 +201,8 @@ _GEMM_INTS = ("M", "N", "K", "ldx", "ldw", "ldc", "ldr", "C1", "ldx2", "epi", "m
 
 
 GN_EPILOGUE = os.environ.get("SDV_GN_EPILOGUE", "1") != "0"     # A/B knob: 0 = every GroupNorm runs its own statistics pass
+SPLIT_K = os.environ.get("SDV_SPLIT_K", "1") != "0"             # A/B knob: 0 = no split-K launches (small-batch regime)
+LAST_SPLIT_K = 1
 
 
 class GnStats:
@@ -299,6 +302,21 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
         a.ln_stats, a.ln_s, a.ln_side = _ptr(ln_stats, F32, "ln_stats"), _ptr(ln_s, F32, "ln_s"), 1
     if gn_out is not None:
         a.gn_out, a.gn_ld = _ptr(gn_out, F32, "gn_out"), gn_out.shape[-1]
+    split_used = False
+    # Split-K for the small-batch regime (sdv_hip.h split_k): plain launches with few rows and a long K ask the library how many
+    # splits it would take and hand it the workspace (the GroupNorm statistics, if asked for, then come out of the second pass).
+    if (SPLIT_K and not fp8 and ln_stats is None and not want_stats and not g["out_mode"] and epi == 0 and batch <= 1 and mode != 4
+            and out_f32 is None and M <= 4096 and K * (1 if mode == 0 else 9) >= 2048):
+        a.split_k = 8
+        S = lib.sdv_gemm_split_k(C.byref(a))
+        if S > 1:
+            ws = torch.empty((S, M, N), dtype=F32, device=x.device)
+            a.out_f32, a.split_k = ws.data_ptr(), S
+            split_used = True
+        else:
+            a.split_k = 0
+    global LAST_SPLIT_K
+    LAST_SPLIT_K = a.split_k if split_used else 1    # (tests / tools: how the last igemm launch was split)
     partials = None
     if want_stats:
         a.stats_out = 16          # (non-null while planning: the tile choice depends on it)

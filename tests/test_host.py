@@ -620,13 +620,20 @@ def test_generate_images_layout_with_a_stub_pipeline(tmp_path):
         generate_images(pipe, "a cat", seeds=[1], output_dir=tmp_path, name="run")
 
 
-def test_bench_reads_the_committed_pmc_profile():
+def test_bench_reads_the_committed_pmc_profile(tmp_path):
     """bench.py folds the committed rocprofv3 --pmc summary of its default batch size into the JSON line (`roofline.traffic`,
-    `attention.mfma_busy_pmc`): the file must parse and carry the two kernels the bench looks up."""
+    `attention.mfma_busy_pmc`) - but only a summary that was collected from THIS tree's kernel sources (the `# csrc=` fingerprint in
+    its first line): the committed one must match, parse and carry the two kernels the bench looks up; a summary
+    of other sources is refused, with the reason."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_module", ROOT / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    fp = bench.csrc_fingerprint()
+    assert len(fp) == 16 and fp == bench.csrc_fingerprint()
+    for name in ("round5_pmc_unet_b128.csv", "round5_bench_b128_kernel_stats.csv"):
+        assert bench.profile_fingerprint(ROOT / "profiles" / name) == fp, \
+            f"profiles/{name} was not collected from the kernel sources of this tree: re-run tools/run_profiles_r5.sh and commit its summaries"
     pmc = bench.pmc_profile(128)
     tr = bench.dominant_kernel_traffic(pmc)
     assert tr and tr["kernel"].startswith("igemm_kernel<4, 2, 2, 5, 64, true")
@@ -634,5 +641,21 @@ def test_bench_reads_the_committed_pmc_profile():
     shapes = [dict(kind="attention", dh=40, Lq=4096, Lk=4096, B=256, H=8, tflops=800.0)]
     att = bench.attention_object(shapes, pmc)
     assert att["shape"]["dh"] == 40 and 0.3 < att["mfma_busy_pmc"] < 0.9 and att["issued_tflops"] == 1120.0
+    rp = bench.rocprof_conv_average(128)
+    assert rp and 500 < rp["avg_launch_us"] < 5000 and rp["launches"] % 51 == 0
     assert bench.pmc_profile(7) == {}                      # no profile for that batch size: the fields stay null
+    # a summary of OTHER kernel sources is not replayed
+    real_root = bench.ROOT
+    try:
+        bench.ROOT = tmp_path
+        (tmp_path / "profiles").mkdir()
+        (tmp_path / "stable_diffusion_videos_amd").symlink_to(real_root / "stable_diffusion_videos_amd")
+        (tmp_path / "include").symlink_to(real_root / "include")
+        body = (real_root / "profiles" / "round5_pmc_unet_b128.csv").read_text().split("\n", 1)[1]
+        (tmp_path / "profiles" / "round5_pmc_unet_b128.csv").write_text("# csrc=0123456789abcdef somebody else's kernels\n" + body)
+        assert bench.pmc_profile(128) == {} and "not replayed" in bench.pmc_profile.stale
+        (tmp_path / "profiles" / "round5_pmc_unet_b128.csv").write_text(body)             # no fingerprint at all (a round-4 file)
+        assert bench.pmc_profile(128) == {} and "unrecorded" in bench.pmc_profile.stale
+    finally:
+        bench.ROOT = real_root
 

@@ -455,6 +455,71 @@ def test_latent_affine(hip, dev):
     assert rel_l2(out.float(), ref) < 3e-3
 
 
+@pytest.mark.parametrize("n,H,C1,C2,Cout,mode,circular", [(2, 8, 1280, 0, 1280, 1, False), (2, 8, 1280, 1280, 1280, 1, False), (8, 8, 1280, 0, 1280, 1, True),
+                                                         (2, 16, 640, 640, 1280, 2, False), (1, 8, 320, 0, 640, 3, False)])
+def test_conv3x3_split_k_small_batches(hip, dev, n, H, C1, C2, Cout, mode, circular):
+    """Split-K (sdv_hip.h split_k) on the low-resolution convs of a 1 - 4-frame call (ResnetBlock2D / downsampler convs of
+    unet(...), stable_diffusion_pipeline.py:418, at walk()'s default batch_size = 1, :571): a handful of output tiles against K up to
+    23 040.  The split launch - partial sums in fp32, second pass adds them in split order, then alpha / step-indexed bias / residual and
+    ONE rounding - against float64 per element (half a bf16 ulp + 1e-5 sum |x w|), bit-identical across repeats, and within an fp32
+    summation-order distance of the unsplit launch; two-source concat, stride 2, nearest-2x, circular padding, bias table."""
+    from stable_diffusion_videos_amd.weights import conv_w
+    x, x2 = rnd((n, H, H, C1), dev, 70), (rnd((n, H, H, C2), dev, 71) if C2 else None)
+    w = rnd((Cout, C1 + C2, 3, 3), dev, 72, (9 * (C1 + C2)) ** -0.5)
+    table = rnd((3, Cout), dev, 73)
+    step = torch.tensor([2], dtype=torch.int32, device=dev)
+    xin = torch.cat([x, x2], -1) if C2 else x
+    ref = conv_ref(xin.double(), w.double(), table[2].double(), mode, circular)
+    mag = conv_ref(xin.double().abs(), w.double().abs(), table[2].double().abs(), mode, circular)
+    Ho = ref.shape[1]
+    res = rnd((n * Ho * Ho, Cout), dev, 74).to(BF16)
+    ref = ref + res.double().view_as(ref)
+    mag = mag + res.double().abs().view_as(ref)
+    kw = dict(nimg=n, H=H, W=H, mode=mode, circular=circular, x2=x2.reshape(-1, C2).to(BF16) if C2 else None, residual=res, step_ptr=step,
+              bias_step_stride=Cout)
+    outs = []
+    for _ in range(3):
+        outs.append(hip.conv3x3(x.reshape(-1, C1).to(BF16), conv_w(w, dev), table, **kw))
+        assert hip.LAST_SPLIT_K >= 2, "this shape is meant to take the split-K path"
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    d = (outs[0].double().view_as(ref) - ref).abs()
+    ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+    assert float((d / (0.5 * ulp + 1e-5 * mag)).max()) <= 1.0
+    prev, hip.SPLIT_K = hip.SPLIT_K, False
+    try:
+        plain = hip.conv3x3(x.reshape(-1, C1).to(BF16), conv_w(w, dev), table, **kw)
+        assert hip.LAST_SPLIT_K == 1
+    finally:
+        hip.SPLIT_K = prev
+    assert rel_l2(outs[0].float(), plain.float()) < 5e-4          # two fp32 summation orders, one bf16 rounding each
+    # the GroupNorm statistics of a split launch leave its second pass: (sum, sumsq) per 32-row block and channel of the STORED values
+    o = hip.conv3x3(x.reshape(-1, C1).to(BF16), conv_w(w, dev), table, gn=True, **kw)
+    assert hip.LAST_SPLIT_K >= 2 and torch.equal(o, outs[0])
+    g = o._sdv_gn
+    of = o.float().view(-1, 32, Cout)
+    assert torch.allclose(g.p[:, 0], of.sum(1), rtol=1e-5, atol=1e-4) and torch.allclose(g.p[:, 1], (of * of).sum(1), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_split_k_dense_and_its_limits(hip, dev):
+    """Dense GEMMs with few rows and a long K split as well (ff.net.2 of the 8 x 8 block at 1 frame per call: M = 128, K = 5120); launches
+    that carry an activation, a LayerNorm fold or statistics, large M, or a short K do not."""
+    x, w, b = rnd((128, 5120), dev, 80).to(BF16), rnd((1280, 5120), dev, 81, 5120 ** -0.5).to(BF16), rnd((1280,), dev, 82)
+    res = rnd((128, 1280), dev, 83).to(BF16)
+    out = hip.linear(x, w, b, residual=res)
+    assert hip.LAST_SPLIT_K >= 2
+    ref = x.double() @ w.double().T + b.double() + res.double()
+    mag = x.double().abs() @ w.double().abs().T + b.double().abs() + res.double().abs()
+    ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+    assert float(((out.double() - ref).abs() / (0.5 * ulp + 1e-5 * mag)).max()) <= 1.0
+    hip.linear(x, w, b, epi=2)
+    assert hip.LAST_SPLIT_K == 1                                  # SiLU epilogue: not a plain launch
+    hip.linear(rnd((8192, 5120), dev, 84).to(BF16), w, b)
+    assert hip.LAST_SPLIT_K == 1                                  # enough tiles without it
+    hip.linear(x[:, :320].contiguous(), w[:, :320].contiguous(), b)
+    assert hip.LAST_SPLIT_K == 1                                  # K too short to share out
+
+
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------

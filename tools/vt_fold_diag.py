@@ -2,7 +2,10 @@
 """Round-5 diagnosis of the round-4 open item (DESIGN.md "Open at the end of round 4"): the column-side LayerNorm fold (ln_side 2,
 the transposed V^T projections) gave batch-size-dependent frames once its row operands went through LDS.
 
-Runs against a ROUND-4 build of the library (the product no longer has this launch form):
+Runs against a ROUND-4 build of the library (the product no longer has this launch form).  Rebuild one with
+    git worktree add /tmp/r4 2b6591d && (cd /tmp/r4 && python -m stable_diffusion_videos_amd.build) && \
+        cp /tmp/r4/stable_diffusion_videos_amd/lib/libsdv_hip.so tools/ubench/libsdv_r4.so
+(the LDS-row-operand variant: the same tree with `constexpr bool ROWV = FEAT == 2;` in csrc/sdv_gemm.hip), then:
     SDV_HIP_LIB=tools/ubench/libsdv_r4.so      python tools/vt_fold_diag.py     # shipped round-4 code (register form on tiles 1/7/9)
     SDV_HIP_LIB=tools/ubench/libsdv_r4_rowv.so python tools/vt_fold_diag.py     # row operands through LDS on every tile (commit 0699fd6's form + explicit FMAs)
 
