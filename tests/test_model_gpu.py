@@ -554,6 +554,9 @@ def test_cache_blocked_forward(hip, dev, fp8, monkeypatch):
     arithmetic; only the row statistics behind the folded LayerNorms may be summed over differently shaped tiles.  Different
     latents AND different contexts per image, ragged last chunk (5 images in chunks of 2), with and without the shared CFG prefix."""
     from stable_diffusion_videos_amd import config as cfgs
+    # (split-K off: whether a launch is split along K depends on its row count, so a 2-image chunk and the 5-image batch would be
+    #  two fp32 summation orders of the low-resolution convs - measured 6e-3 - and this test is about the chunk loop, not about that)
+    monkeypatch.setattr(hip, "SPLIT_K", False)
     for c in (cfgs.tiny_unet(), cfgs.sd14_unet()):
         name = "sd14" if c.cross_attention_dim == 768 else "tiny"
         if fp8 and name == "tiny":
