@@ -62,6 +62,40 @@ def test_argument_validation_without_gpu(hip):
     assert lib.sdv_gemm_bf16(ctypes.byref(a), None) == -1 and b"ln_side" in lib.sdv_last_error()
 
 
+def test_split_k_planning_without_gpu(hip):
+    """sdv_gemm_split_k is pure host logic (sdv_hip.h "split_k"): the small-batch shapes of the UNet split, everything the second pass
+    cannot finish - or that fills the chip by itself - does not.  Shapes: ResBlock conv3x3 1280 -> 1280 at the 8 x 8 level of a 1 / 4 /
+    16 / 128-frame call (M = 2 B x 64 rows), ff.net.2 of the mid block, a K = 320 projection."""
+    lib = hip.load()
+
+    def plan(M, N, K, mode=0, **kw):
+        a = hip.GemmArgs()
+        a.X = a.W = a.C = 16
+        a.M, a.N, a.K, a.ldx, a.ldw, a.ldc, a.mode = M, N, K, K, K * (9 if mode else 1), N, mode
+        if mode:
+            a.Hin = a.Win = a.Hout = a.Wout = 8
+        a.split_k = 8
+        for k, v in kw.items():
+            setattr(a, k, v)
+        s = lib.sdv_gemm_split_k(ctypes.byref(a))
+        assert s >= 1, lib.sdv_last_error()
+        return s
+
+    assert plan(128, 1280, 1280, mode=1) >= 4          # 1 frame per call: a handful of tiles, 180 K slabs each
+    assert plan(512, 1280, 1280, mode=1) >= 2          # 4 frames per call
+    assert plan(2048, 1280, 1280, mode=1) == 1         # 16 frames per call: 160 tiles of 128 x 128 - too many to split
+    assert plan(16384, 1280, 1280, mode=1) == 1        # 128 frames per call: the 256 x 320 tile, one per CU
+    assert plan(128, 1280, 5120) >= 2                  # ff.net.2 of the 8 x 8 block
+    assert plan(128, 1280, 320) == 1                   # 5 K slabs: nothing to share out
+    assert plan(128, 1280, 5120, epi=2) == 1           # an activation: the second pass only knows alpha / bias / residual
+    assert plan(128, 1280, 5120, batch=2) == 1 and plan(128, 1280, 5120, out_mode=1, out_f32=16) == 1
+    assert plan(128, 1280, 5120, ln_side=1, ln_stats=16, ln_s=16) == 1 and plan(128, 1280, 5120, stats_out=16) == 1
+    assert plan(128, 1280, 5120, tile=6) == 1          # a forced 8-wave tile (tests: hip.FORCE_TILE) never splits
+    for M in (64, 128, 512, 1024):                     # never fewer than 16 K slabs per split, never more than 8 splits
+        s = plan(M, 1280, 1280, mode=1)
+        assert s <= 8 and 180 // s >= 16
+
+
 def test_product_fails_loudly_without_gpu(hip):
     from stable_diffusion_videos_amd import StableDiffusionWalkPipeline, slerp
     with pytest.raises(hip.SdvHipError, match="GPU"):
