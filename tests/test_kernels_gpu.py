@@ -109,6 +109,29 @@ def test_gemm_geglu(hip, dev, tile):
     assert rel_l2(out.float(), ref) < MFMA_TOL
 
 
+def test_geglu_gate_saturates_at_infinity(hip, dev):
+    """the rearranged exact-erf GELU of the GEGLU epilogue (sdv_common.h gelu_erf_fast_f) ended in fma(-|x|, h, max(x, 0)) -
+    at a gate of +inf that is fma(-inf, 0, inf) = NaN where gelu(+inf) = +inf, so an overflowed gate poisoned the residual stream instead of
+    saturating.  |x| is capped now: gate +inf -> value * inf = +-inf (no NaN), gate -inf -> value * (-0) = 0, NaN stays NaN."""
+    from stable_diffusion_videos_amd.weights import geglu_interleave
+    M, K, N = 64, 64, 64                                   # N = [32 value | 32 gate] columns
+    x = torch.ones((M, K), device=dev)
+    w = torch.zeros((N, K), device=dev)
+    w[:32] = 1.0 / K                                       # value = 1 + bias_value
+    b = torch.zeros(N, device=dev)
+    b[:32] = 1.0                                           # value = 2
+    b[32:40] = 3.0e38                                      # gate pre-activation finite but huge: gelu = itself
+    b[40:48] = float("inf")                                # gate +inf
+    b[48:56] = float("-inf")                               # gate -inf
+    b[56:64] = 2.0                                         # an ordinary gate
+    for tile in (0, 1, 6):
+        out = hip.linear(x.to(BF16), geglu_interleave(w).to(BF16), geglu_interleave(b), epi=1, tile=tile).float()
+        assert not torch.isnan(out).any(), tile
+        assert torch.isinf(out[:, 0:16]).all() and (out[:, 0:16] > 0).all(), tile       # 2 * 3e38 and 2 * inf
+        assert (out[:, 16:24] == 0).all(), tile
+        assert torch.allclose(out[:, 24:32], torch.full((M, 8), 2.0 * float(F.gelu(torch.tensor(2.0))), device=dev), rtol=1e-2), tile
+
+
 def test_gemm_refuses_the_launch_forms_removed_in_abi_10(hip, dev):
     """ABI 10 dropped the experiments of rounds 2-4 from the product library: the LDS-ring tiles 12 / 13, the transposed 320 x 256
     tile 14 and the column-side LayerNorm fold it carried (the V^T projections - replaced by the fused QKV projection + row-major V
