@@ -437,7 +437,7 @@ class StableDiffusionWalkPipeline:
             ent = self._graphs.pop(old_key)
             ent["graph"] = ent["one_step"] = None
             del ent
-            # the cross-attention K / V^T buffers and V^T workspaces are kept per batch size because captured graphs hold raw
+            # the cross-attention K / V^T buffers of the text context are kept per batch size because captured graphs hold raw
             # pointers into them: once no cached graph runs at that batch size any more they go too (a resumed walk with many
             # short runs would otherwise leave one set per distinct batch size behind)
             if not any(k[1] == old_key[1] for k in self._graphs) and old_key[1] != nimg:

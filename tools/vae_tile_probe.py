@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""Is the tiny VAE decode independent of the igemm tile (cost model vs forced 256 x 320), block by block - and, inside the first block
+that is not, which intermediate or which epilogue statistics tensor differs?  Found the re-associated GroupNorm statistics of the
+phase-form up-conv (DESIGN.md status row 1b).  usage: python tools/vae_tile_probe.py [latents.pt]"""
 import sys
 from pathlib import Path
 import torch
@@ -6,7 +10,7 @@ from stable_diffusion_videos_amd import StableDiffusionWalkPipeline, engine, hip
 pipe = StableDiffusionWalkPipeline.from_pretrained("tiny", arch="tiny").to("cuda")
 g = torch.Generator(device="cuda").manual_seed(1)
 lat = torch.randn((4, 16, 16, 4), device="cuda", generator=g) * 0.18215
-dbg = Path("/root/repo/gpurun_out/debug_latents.pt")
+dbg = Path(sys.argv[1]) if len(sys.argv) > 1 else Path("/nonexistent")     # optional: latents [B, 4, h, w] saved by a failing run
 if dbg.exists():
     lat = hip.nchw_to_nhwc(torch.load(dbg).cuda())
     print("latents from", dbg, tuple(lat.shape), "abs max", float(lat.abs().max()), "std", float(lat.std()))
