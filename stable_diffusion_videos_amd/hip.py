@@ -305,8 +305,9 @@ def _igemm_impl(x, w, out, bias, residual, x2, ln_stats, ln_s, step_ptr, out_f32
     split_used = False
     # Split-K for the small-batch regime (sdv_hip.h split_k): plain launches with few rows and a long K ask the library how many
     # splits it would take and hand it the workspace (the GroupNorm statistics, if asked for, then come out of the second pass).
+    # (alpha_cols - alpha on the leading columns only - is not something the second pass knows: such launches stay unsplit)
     if (SPLIT_K and not fp8 and ln_stats is None and not want_stats and not g["out_mode"] and epi == 0 and batch <= 1 and mode != 4
-            and out_f32 is None and M <= 4096 and K * (1 if mode == 0 else 9) >= 2048):
+            and out_f32 is None and not g["alpha_cols"] and M <= 4096 and K * (1 if mode == 0 else 9) >= 2048):
         a.split_k = 8
         S = lib.sdv_gemm_split_k(C.byref(a))
         if S > 1:
