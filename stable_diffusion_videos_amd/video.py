@@ -196,6 +196,12 @@ def _frames_uint8(frames_or_frame_dir, glob_pattern: str) -> List[np.ndarray]:
     return [np.ascontiguousarray(x) for x in t.cpu().numpy().astype(np.uint8)]
 
 
+# What the last make_video_pyav call wrote: {"path", "video": "h264 (libx264)" | "h264 (I_PCM)" | "mjpeg", "audio": None | "aac" | "pcm_s16le",
+# "why"}.  The codec of a walk's mp4 depends on the environment (torchvision / pyav present?) and, without them, on the stream size -
+# a caller that cares (a browser cannot play Motion-JPEG) reads it here instead of parsing the log.
+LAST_CODEC: dict = {}
+
+
 def make_video_pyav(frames_or_frame_dir: Union[str, Path, torch.Tensor] = "./images", audio_filepath=None, fps: int = 30,
                     audio_offset: int = 0, audio_duration: int = 2, sr: int = 22050,
                     output_filepath: Union[str, Path] = "output.mp4", glob_pattern: str = "*.png"):
@@ -217,8 +223,11 @@ def make_video_pyav(frames_or_frame_dir: Union[str, Path, torch.Tensor] = "./ima
                         audio_codec="aac", options={"crf": "10", "pix_fmt": "yuv420p"})
         else:
             write_video(output_filepath, stack, fps=fps, options={"crf": "10", "pix_fmt": "yuv420p"})
+        LAST_CODEC.clear()
+        LAST_CODEC.update(path=output_filepath, video="h264 (libx264)", audio="aac" if audio_filepath else None, why="torchvision / pyav present")
         return output_filepath
     audio = None
+    why = "SDV_VIDEO_CODEC" if os.environ.get("SDV_VIDEO_CODEC") else "default"
     codec = (os.environ.get("SDV_VIDEO_CODEC") or DEFAULT_CODEC).lower()
     if codec not in ("h264", "mjpeg"):
         raise ValueError(f"SDV_VIDEO_CODEC={codec!r}: expected 'h264' or 'mjpeg'")
@@ -229,16 +238,21 @@ def make_video_pyav(frames_or_frame_dir: Union[str, Path, torch.Tensor] = "./ima
             logger.warning("%d frames of %dx%d as uncompressed I_PCM H.264 would be %.1f GB: writing Motion-JPEG instead "
                            "(set SDV_VIDEO_CODEC=h264 to force, SDV_H264_PCM_MAX_BYTES to move the limit)", len(frames), w, h, est / 1e9)
             codec = "mjpeg"
+            why = f"estimated I_PCM stream {est} bytes > {H264_PCM_MAX_BYTES}"
         else:
             logger.info("H.264 I_PCM video track: %d frames of %dx%d = %.1f MB (uncompressed, 1.5 bytes per pixel)",
                         len(frames), w, h, est / 1e6)
     if codec == "h264" and (h % 2 or w % 2):
         logger.warning("odd frame size %dx%d: yuv420p needs even sizes, writing Motion-JPEG instead", w, h)
         codec = "mjpeg"
+        why = f"odd frame size {w}x{h}"
     if audio_filepath:
         from .audio import load_audio
         logger.warning("no ffmpeg/pyav in this environment: the audio track is uncompressed 16-bit PCM instead of AAC")
         audio, _ = load_audio(audio_filepath, sr=sr, mono=True, offset=audio_offset, duration=audio_duration)
+    LAST_CODEC.clear()
+    LAST_CODEC.update(path=output_filepath, video="h264 (I_PCM)" if codec == "h264" else "mjpeg", audio="pcm_s16le" if audio is not None else None,
+                      why=why)
     if codec == "h264":
         return write_h264_mp4(frames, w, h, fps, output_filepath, audio=audio, sr=sr)
     from PIL import Image

@@ -421,10 +421,19 @@ def test_codec_selection_and_odd_sizes(tmp_path, monkeypatch):
     buf = open(make_video_pyav(odd, fps=8, output_filepath=tmp_path / "odd.mp4"), "rb").read()
     lo, hi = find(buf, ("moov", "trak", "mdia", "minf", "stbl", "stsd"))
     assert parse_boxes(buf, lo + 8, hi)[0][0] == "mp4v"
+    from stable_diffusion_videos_amd import video
+    assert video.LAST_CODEC["video"] == "mjpeg" and "odd frame size" in video.LAST_CODEC["why"]      # the choice is recorded
     even = odd[:, :, :32]
     buf = open(make_video_pyav(even, fps=8, output_filepath=tmp_path / "even.mp4"), "rb").read()
     lo, hi = find(buf, ("moov", "trak", "mdia", "minf", "stbl", "stsd"))
     assert parse_boxes(buf, lo + 8, hi)[0][0] == "avc1"
+    assert video.LAST_CODEC["video"] == "h264 (I_PCM)" and video.LAST_CODEC["path"].endswith("even.mp4") and video.LAST_CODEC["audio"] is None
+    # ... including the size fallback: above the I_PCM limit the default writer switches to Motion-JPEG and says why
+    monkeypatch.setattr(video, "H264_PCM_MAX_BYTES", 1000)
+    make_video_pyav(even, fps=8, output_filepath=tmp_path / "big.mp4")
+    assert video.LAST_CODEC["video"] == "mjpeg" and "I_PCM stream" in video.LAST_CODEC["why"]
+    monkeypatch.undo()
+    monkeypatch.delenv("SDV_VIDEO_CODEC", raising=False)
     monkeypatch.setenv("SDV_VIDEO_CODEC", "vp9")
     with pytest.raises(ValueError, match="SDV_VIDEO_CODEC"):
         make_video_pyav(even, fps=8, output_filepath=tmp_path / "x.mp4")
