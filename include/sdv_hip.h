@@ -133,7 +133,8 @@ typedef struct sdv_gemm_args {
      * split_k > 1 on entry (with out_mode 0 and out_f32 = a workspace of [split_k][M][N] floats): the launch MAY give every output tile
      * to up to split_k workgroups, each taking a contiguous range of K slabs and leaving its fp32 partial sums in the workspace; a
      * second pass adds them in split order (deterministic), applies alpha / bias / residual and rounds once.  Plain launches only
-     * (epi 0, no fold / statistics / fp8 / typed output / batch / phase form), 4-wave tiles only (1 - 3), >= 1024 K values per split.
+     * (epi 0, no alpha_cols / fold / statistics / fp8 / typed output / batch / phase form, C and R 8-byte aligned - anything else
+     * runs unsplit), 4-wave tiles only (1 - 3), >= 1024 K values per split.
      * sdv_gemm_split_k(args) tells how many splits a launch would take (1 = none), so the caller can size the workspace. */
     int32_t split_k;
 } sdv_gemm_args;

@@ -102,7 +102,7 @@ SDV_DEVICE float wave_max(float v) {
 }
 
 // ---- host side error plumbing ------------------------------------------------------------------
-void sdv_set_error(const char* fmt, ...);
+__attribute__((visibility("hidden"))) void sdv_set_error(const char* fmt, ...);   // (internal: not part of the C ABI)
 #define SDV_REQUIRE(cond, ...)            \
     do {                                  \
         if (!(cond)) {                    \

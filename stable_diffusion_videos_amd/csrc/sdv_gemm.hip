@@ -1472,8 +1472,11 @@ static int sdv_gemm_impl(const sdv_gemm_args* args, void* stream, int plan) {
     // residual - no activation, fold, statistics, typed output, batch or phase form), only when the tiles leave most CUs idle, never
     // fewer than 16 K slabs (1024 K values) per split, at most what the caller's workspace holds.
     const long long kslabs = (long long)(a.K / 64) * (a.mode ? 9 : 1);
+    // (alpha_cols: the second pass scales EVERY column by alpha - a launch that scales only its leading columns is never split;
+    //  C / R 8-byte aligned: the second pass moves them as uint2)
     const bool split_ok = split_cap > 1 && !a.fp8 && !a.ln_side && !a.stats_out && !a.out_mode && a.epi == 0 && a.batch <= 1 &&
-                          a.mode != 4 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0);
+                          a.mode != 4 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && !a.alpha_cols &&
+                          ((((uintptr_t)a.C | (uintptr_t)a.R) & 7) == 0) && ((((uintptr_t)a.out_f32) & 15) == 0);
     auto splits_for = [&](long long nblocks) -> int {
         if (!split_ok || nblocks > 128 || kslabs < 32) return 1;
         long long sk = 256 / nblocks;

@@ -122,7 +122,7 @@ class StableDiffusionWalkPipeline:
         self._device = torch.device("cpu")
         self._graphs: Dict[tuple, dict] = {}
         self._graph_pool = None            # the private memory pool every captured step allocates from (see _capture)
-        self.max_cached_graphs = 4         # LRU bound on captured denoise-step graphs (each has its own memory pool)
+        self.max_cached_graphs = 4         # LRU bound on captured denoise-step graphs (all share ONE private pool, which only shrinks when every graph is dropped)
         self._uncond_cache: Dict[str, torch.Tensor] = {}
         self._sched_cache: Dict[tuple, tuple] = {}
         self._writer: Optional[FrameWriter] = None
@@ -430,9 +430,13 @@ class StableDiffusionWalkPipeline:
     def _graph_entry(self, key: tuple, nimg: int, B: int, h: int, w: int, cfg: bool, guidance: float, coefs, eta_noise):
         """Static buffers + a captured hipGraph of ONE denoise step (UNet forward + CFG/DDIM update + step++)."""
         if key in self._graphs:
-            self._graphs[key] = self._graphs.pop(key)          # most recently used last
-            return self._graphs[key]
-        while len(self._graphs) >= self.max_cached_graphs:     # every captured step owns a multi-GB private pool
+            ent = self._graphs[key] = self._graphs.pop(key)    # most recently used last
+            # an entry made while use_graphs was off (or whose capture failed) is captured behind its next eager step once graphs
+            # are on again - otherwise it would run eagerly for ever (ADVICE r5)
+            if self.use_graphs and ent["graph"] is None and not ent.get("capture_failed"):
+                ent["capture_pending"] = True
+            return ent
+        while len(self._graphs) >= self.max_cached_graphs:     # bound the static buffers + cross-attention K / V^T sets kept alive
             old_key = next(iter(self._graphs))
             ent = self._graphs.pop(old_key)
             ent["graph"] = ent["one_step"] = None
@@ -498,19 +502,28 @@ class StableDiffusionWalkPipeline:
         import gc
         gc_was_on = gc.isenabled()
         gc.disable()
+        ent["capture_pending"] = False          # whatever happens below, the capture is not retried on every following step
+        err = None
         try:
             with torch.cuda.stream(side):
                 g.capture_begin(pool=self._graph_pool, capture_error_mode=mode)
                 try:
                     ent["one_step"]()
-                finally:
+                except BaseException as e:      # keep the ORIGINAL error: capture_end() on a broken capture raises one of its own
+                    err = e
+                try:
                     g.capture_end()
+                except BaseException as e:
+                    if err is None:
+                        err = e
         finally:
             if gc_was_on:
                 gc.enable()
-        torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(side)
+        if err is not None:
+            ent["capture_failed"] = True        # this entry keeps running eagerly
+            raise err
         ent["graph"] = g
-        ent["capture_pending"] = False
         self.last_graph_build = {"capture_s": time.perf_counter() - t0}
 
     @torch.no_grad()

@@ -91,6 +91,10 @@ def test_split_k_planning_without_gpu(hip):
     assert plan(128, 1280, 5120, batch=2) == 1 and plan(128, 1280, 5120, out_mode=1, out_f32=16) == 1
     assert plan(128, 1280, 5120, ln_side=1, ln_stats=16, ln_s=16) == 1 and plan(128, 1280, 5120, stats_out=16) == 1
     assert plan(128, 1280, 5120, tile=6) == 1          # a forced 8-wave tile (tests: hip.FORCE_TILE) never splits
+    # the second pass scales EVERY column by alpha and moves C / R as 8-byte pieces: a C caller that asks for alpha on the leading
+    # columns only (a fused [Q | K] projection), or hands over a 2-byte aligned output, gets an unsplit launch, not a wrong one
+    assert plan(128, 1280, 5120, alpha=0.125, alpha_cols=640) == 1 and plan(128, 1280, 5120, alpha=0.125) >= 2
+    assert plan(128, 1280, 5120, C=18) == 1 and plan(128, 1280, 5120, R=18, ldr=1280) == 1 and plan(128, 1280, 5120, R=16, ldr=1280) >= 2
     for M in (64, 128, 512, 1024):                     # never fewer than 16 K slabs per split, never more than 8 splits
         s = plan(M, 1280, 1280, mode=1)
         assert s <= 8 and 180 // s >= 16
