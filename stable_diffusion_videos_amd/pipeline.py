@@ -486,7 +486,10 @@ class StableDiffusionWalkPipeline:
         two steps never run concurrently, so a new batch size costs the pool only what it needs beyond the largest so far."""
         t0 = time.perf_counter()
         dev = self.device
-        if self._graph_pool is None:
+        # The shared pool lives as long as one graph captured into it does: once every captured step has been dropped (fp8 counter
+        # switch, LRU eviction of the last one, a caller clearing ``_graphs``) PyTorch forgets the pool, and capturing into the stale
+        # handle trips an internal assert of its caching allocator (seen when the collector had already freed the old graphs).
+        if self._graph_pool is None or not any(e.get("graph") is not None for e in self._graphs.values()):
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread may touch the runtime while this thread captures: only this
