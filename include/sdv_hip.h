@@ -155,6 +155,30 @@ int sdv_gemm_set_grid_limit(int n);
 int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, int32_t C, float eps, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused GEGLU feed-forward of a BasicTransformerBlock, ONE launch (csrc/sdv_ffn.hip):
+ *     out[m][:] = X[m][:] + b2 + W2 . ( v * gelu(g) ),   [v | g] = LayerNorm(X[m]) W1^T + b1
+ * Replaces norm3 -> ff.net.0 (GEGLU) -> ff.net.2 -> + residual of diffusers' BasicTransformerBlock inside unet(...)
+ * (stable_diffusion_pipeline.py:418) - as two sdv_gemm_bf16 launches (epi 1 with ln_side 1, then a residual GEMM) the
+ * [M][4C] GEGLU output went through HBM; here a workgroup keeps a 128-token panel on chip and streams the weights.
+ *   X        [M][ldx] bf16, un-normalised (the residual stream);  ln_stats [M][2] fp32 (mean, rstd) of its rows
+ *            (sdv_rowstats_finalize of the producer's stats_out)
+ *   W1       [8C][C] bf16 = gamma o ff.net.0.proj.weight, rows GEGLU-interleaved in 32-row tiles [16 value | 16 gate]
+ *            (the layout sdv_gemm_bf16's epi 1 takes)
+ *   W1x      [8C][16] bf16, same row order: the LayerNorm fold's per-column terms as one more k-step of the matrix product.
+ *            With s = row sums of W1 (fp32) and t = W beta + b (fp32), each split into three bf16 pieces (h + m + l):
+ *            row = (s_h s_h s_m s_h s_l s_m t_h t_h | t_m t_h t_l t_m 0 0 0 0); the kernel multiplies it with the token's
+ *            (m_h m_m m_h m_l m_h m_m r_h r_m | r_h r_l r_h r_m 0 0 0 0), m = -mean, r = 1 / rstd - the six leading cross terms
+ *            of each product, 24 bits, accumulated in fp32:  LN(x) W^T + b = rstd (x W1^T - mean s + t / rstd)
+ *   W2p      [C][4C] bf16 = ff.net.2.weight with its K axis permuted inside every block of 16: position 8 a + 4 b + e holds
+ *            column 8 b + 4 a + e (a, b in {0, 1}, e in 0..3) - the order in which the MFMA accumulator layout hands the GEGLU
+ *            outputs of a lane over as the next contraction's B operand;  bias2 [C]
+ *   out      [M][ldo] bf16 (may alias nothing of the inputs)
+ * C must be 320 (the 64 x 64 level of SD-1.x / the 96 x 96 level of SD-2.x at 768 x 768: wider levels keep the two-launch form -
+ * their weights do not stay L2-resident per panel).  M is arbitrary (rows past M are not stored). */
+int sdv_ffn_geglu_bf16(const sdv_bf16* X, const float* ln_stats, int64_t M, int32_t C, int32_t ldx, const sdv_bf16* W1, const sdv_bf16* W1x,
+                       const sdv_bf16* W2p, const float* bias2, sdv_bf16* out, int32_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Flash-style attention, softmax(Q K^T * scale) V, never materialising the score matrix.
  * Replaces CrossAttention.forward inside the UNet (self: Lk = Lq; cross: Lk = 77).
  *   Q  [B][Lq][ldq]   head h at columns [h*dh, (h+1)*dh)

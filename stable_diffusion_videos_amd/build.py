@@ -24,12 +24,15 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", str(INCLUDE)]
 # fast-math only where it buys throughput (MFMA epilogues / softmax); the interpolation + scheduler kernels keep
 # IEEE division so that slerp(0) == v0 and slerp(1) == v1 hold exactly, as in the reference's numpy arithmetic.
-FAST_MATH = {"sdv_gemm.hip", "sdv_attention.hip", "sdv_norm.hip"}
+FAST_MATH = {"sdv_gemm.hip", "sdv_attention.hip", "sdv_norm.hip", "sdv_ffn.hip"}
 FAST_FLAGS = ["-ffast-math", "-fno-finite-math-only"]
 # attention: MFMA results are consumed by the softmax VALU code straight away - keep them in VGPRs (no
 # v_accvgpr_read/write traffic; 123+32 -> 128 registers, 3 -> 4 waves/SIMD for the 40/64-wide heads)
 EXTRA_FLAGS = {"sdv_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "sdv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "sdv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # fused feed-forward: one wave per SIMD with all 512 registers (AGPR-form MFMAs: no vgpr-form here); its VALU stream is
+               # laid out by hand beside the MFMAs, where packed fp32 ops (v_pk_fma_f32 out of the SLP vectoriser) are an anti-lever
+               "sdv_ffn.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:

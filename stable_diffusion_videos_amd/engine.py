@@ -25,7 +25,7 @@ import torch
 
 from . import hip
 from .config import UNetConfig, VAEConfig
-from .weights import StateDict, conv_w, conv_w_c4, geglu_interleave, lin_w, ln_fold, upconv_phase_w, vec
+from .weights import StateDict, conv_w, conv_w_c4, ffn_fold_columns, ffn_w2_permute, geglu_interleave, lin_w, ln_fold, upconv_phase_w, vec
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -184,6 +184,12 @@ class _Transformer:
         self.wff1, self.sff1, self.bff1 = ln_fold(geglu_interleave(sd[f"{b}.ff.net.0.proj.weight"]), *ln3,
                                                   geglu_interleave(sd[f"{b}.ff.net.0.proj.bias"]), device)
         self.wff2, self.bff2 = lin_w(sd[f"{b}.ff.net.2.weight"], device), vec(sd[f"{b}.ff.net.2.bias"], device)
+        # C = 320 (the 64 x 64 level): norm3 -> ff.net.0 -> GEGLU -> ff.net.2 -> + residual is ONE launch (sdv_ffn_geglu_bf16) - the
+        # hidden activations never leave the registers; the LayerNorm fold's per-column terms ride in the matrix product (w1x)
+        self.ffn_fused = hip.FFN_FUSED and self.C == 320
+        if self.ffn_fused:
+            self.w1x = ffn_fold_columns(self.sff1, self.bff1)
+            self.w2p = ffn_w2_permute(self.wff2)
         self.groups = groups
         # A/B switch (tools/unet_ab.py): SDV_LN_FOLD=0 keeps the three LayerNorms as kernels of their own
         self.fold = os.environ.get("SDV_LN_FOLD", "1") != "0"
@@ -273,8 +279,11 @@ class _Transformer:
         _tap(self.name, "tf_attn2", x=h_in, out=h, nimg=nb, H=H, W=W, shared_prefix=shared_prefix)
         h_in = h
         # --- GEGLU feed-forward (LN3 inside ff.net.0) ---
-        g = hip.linear(h, self.wff1, self.bff1, epi=1, ln=(st3, self.sff1))   # [M, 4C]
-        h = hip.linear(g, self.wff2, self.bff2, residual=h)
+        if self.ffn_fused:
+            h = hip.ffn_geglu(h, st3, self.wff1, self.w1x, self.w2p, self.bff2)
+        else:
+            g = hip.linear(h, self.wff1, self.bff1, epi=1, ln=(st3, self.sff1))   # [M, 4C]
+            h = hip.linear(g, self.wff2, self.bff2, residual=h)
         _tap(self.name, "tf_ff", x=h_in, out=h, nimg=nimg, H=H, W=W)
         if not shared_prefix:
             out = hip.linear(h, self.w_out, self.b_out, residual=x, out=out, gn_hw=HW)

@@ -42,7 +42,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 10    # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 11    # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "sdv_gemm_set_persistent": (C.c_int, [C.c_int]),
     "sdv_gemm_set_grid_limit": (C.c_int, [C.c_int]),
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "sdv_ffn_geglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -491,6 +492,38 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     [B*Lk][ldv] rows, head h at columns v_off + [h*dh, (h+1)*dh): the V third of a fused [Q | K | V] projection."""
     _k_attention(q, k, vt, out, [B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, q_off, k_off, v_off], float(scale), bool(causal),
                  bool(q_prescaled), bool(v_rowmajor))
+
+
+def _ffn_geglu_impl(x, ln_stats, w1, w1x, w2p, bias2, out):
+    lib = load()
+    M, C = x.shape
+    if tuple(w1.shape) != (8 * C, C) or tuple(w1x.shape) != (8 * C, 16) or tuple(w2p.shape) != (C, 4 * C) or not (
+            w1.is_contiguous() and w1x.is_contiguous() and w2p.is_contiguous()):
+        raise SdvHipError(f"ffn_geglu: weights must be contiguous [8C, C] / [8C, 16] / [C, 4C] for C = {C}, got {tuple(w1.shape)} / "
+                          f"{tuple(w1x.shape)} / {tuple(w2p.shape)}")
+    if ln_stats.numel() != 2 * M or bias2.numel() != C or out.shape != x.shape:
+        raise SdvHipError("ffn_geglu: vector / output sizes do not match the activation")
+    args = (_ptr(x, BF16, "X"), _ptr(ln_stats, F32, "ln_stats"), M, C, x.stride(0), _ptr(w1, BF16, "W1"), _ptr(w1x, BF16, "W1x"),
+            _ptr(w2p, BF16, "W2p"), _ptr(bias2, F32, "bias2"), _ptr(out, BF16, "out"), out.stride(0))
+    # algorithmic work: both projections (2 M (8C C + C 4C)); bytes: x in, out back (the hidden activations never touch HBM)
+    _launch("ffn_geglu", dict(M=M, N=8 * C, K=C, flops=2.0 * M * 12 * C * C, bytes=4.0 * M * C),
+            lambda: _check(lib.sdv_ffn_geglu_bf16(*args, _stream()), "sdv_ffn_geglu_bf16"))
+
+
+_k_ffn_geglu = _defop("k_ffn_geglu(Tensor x, Tensor ln_stats, Tensor w1, Tensor w1x, Tensor w2p, Tensor bias2, Tensor(a!) out) -> ()", _ffn_geglu_impl)
+FFN_FUSED = os.environ.get("SDV_FFN_FUSED", "1") != "0"     # A/B knob: 0 = the C = 320 feed-forward as two igemm launches (round 5)
+
+
+def ffn_geglu(x: torch.Tensor, ln_stats: torch.Tensor, w1: torch.Tensor, w1x: torch.Tensor, w2p: torch.Tensor, bias2: torch.Tensor,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x + ff.net.2(GEGLU(ff.net.0(LayerNorm(x)))) in ONE launch (``torch.ops.sdv.k_ffn_geglu`` -> sdv_ffn_geglu_bf16, C = 320 only).
+    ``w1``: the gamma-folded, GEGLU-interleaved ff.net.0 weight of ``weights.ln_fold(weights.geglu_interleave(...))``; ``w1x``:
+    ``weights.ffn_fold_columns(s, t)`` of the same call; ``w2p``: ``weights.ffn_w2_permute(ff.net.2.weight)``; ``ln_stats`` [M, 2]:
+    (mean, rstd) of the rows of ``x`` (the producer's ``want_stats``)."""
+    if out is None:
+        out = torch.empty_like(x)
+    _k_ffn_geglu(x, ln_stats, w1, w1x, w2p, bias2, out)
+    return out
 
 
 _fp8_sat_ref: Optional[torch.Tensor] = None

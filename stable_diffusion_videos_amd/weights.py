@@ -358,6 +358,34 @@ def ln_fold(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Opti
     return wp.contiguous(), s, (t * scale).contiguous()
 
 
+def ffn_w2_permute(w: torch.Tensor) -> torch.Tensor:
+    """ff.net.2.weight [C, 4C] for the fused feed-forward (sdv_ffn_geglu_bf16): inside every block of 16 hidden channels position
+    8 a + 4 b + e holds channel 8 b + 4 a + e.  The GEGLU outputs of a lane sit in the 32x32 MFMA accumulator layout - lane half a
+    owns channels 8 b + 4 a + e of a 16-channel tile - and are handed to ff.net.2's MFMA as its B operand as they are, where lane
+    half a supplies K positions 8 a .. 8 a + 7: the contraction is unchanged as long as W2 walks K in the same order."""
+    n, k = w.shape
+    assert k % 16 == 0
+    return w.reshape(n, k // 16, 2, 2, 4).permute(0, 1, 3, 2, 4).reshape(n, k).contiguous()
+
+
+def ffn_fold_columns(s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """The weight side of the fused feed-forward's fold k-step (sdv_ffn_geglu_bf16 ``W1x`` [N, 16] bf16): the LayerNorm fold's
+    per-column terms of ``ln_fold`` - ``s`` (row sums of gamma o W) and ``t`` (W beta + b), fp32 - each split into three bf16
+    pieces (h + m + l = the fp32 value to 24 bits) and laid out so that, against the kernel's token vector
+    (m_h m_m m_h m_l m_h m_m r_h r_m | r_h r_l r_h r_m 0 0 0 0) with m = -mean, r = 1 / rstd, the twelve products are the six
+    leading cross terms of (-mean) s and of t / rstd: the matrix core adds  - mean s + t / rstd  to x W'^T in fp32."""
+    def split3(x):
+        x = x.detach().to(torch.float32)
+        h = x.to(torch.bfloat16)
+        m = (x - h.float()).to(torch.bfloat16)
+        lo = (x - h.float() - m.float()).to(torch.bfloat16)
+        return h, m, lo
+    sh, sm, sl = split3(s)
+    th, tm, tl = split3(t)
+    z = torch.zeros_like(sh)
+    return torch.stack([sh, sh, sm, sh, sl, sm, th, th, tm, th, tl, tm, z, z, z, z], dim=1).contiguous()
+
+
 def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
     """ff.net.0.proj rows are [value(4C) | gate(4C)]; the GEGLU epilogue wants every 32-row MFMA tile to hold
     [16 value rows | the 16 gate rows of the same channels], so that value and gate of a channel meet in the same

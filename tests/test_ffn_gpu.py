@@ -1,0 +1,118 @@
+"""The fused GEGLU feed-forward (sdv_ffn_geglu_bf16, csrc/sdv_ffn.hip; torch.ops.sdv.k_ffn_geglu) against a float64 evaluation of
+norm3 -> ff.net.0 -> GEGLU -> ff.net.2 -> + residual (diffusers' BasicTransformerBlock inside unet(...),
+stable_diffusion_pipeline.py:418) on the operands the kernel sees, element by element, and against the two-launch form it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+C = 320
+
+
+def _weights(dev, seed=0):
+    from stable_diffusion_videos_amd.weights import ffn_fold_columns, ffn_w2_permute, geglu_interleave, ln_fold
+    g = torch.Generator().manual_seed(seed)
+    w1 = torch.randn(8 * C, C, generator=g) * C ** -0.5
+    b1 = torch.randn(8 * C, generator=g) * 0.2
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).to(BF16)
+    b2 = torch.randn(C, generator=g) * 0.2
+    gamma, beta = 1.0 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    w1p, s1, t1 = ln_fold(geglu_interleave(w1), gamma, beta, geglu_interleave(b1), dev)
+    return dict(w1p=w1p, s1=s1, t1=t1, w1x=ffn_fold_columns(s1, t1), w2=w2.to(dev), w2p=ffn_w2_permute(w2).to(dev), b2=b2.to(dev, F32))
+
+
+def _rows(M, dev, seed, common_mode=3.0):
+    """rows like the UNet's residual stream: a common mode of several sigma, sigma between 0.03 and 2"""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    mu = torch.randn(M, 1, device=dev, generator=g) * common_mode
+    sd = torch.exp(torch.empty(M, 1, device=dev).uniform_(-3.4, 0.7, generator=g))
+    x = (mu + sd * torch.randn((M, C), device=dev, generator=g)).to(BF16)
+    xf = x.float()
+    st = torch.stack([xf.mean(1), torch.rsqrt(xf.var(1, unbiased=False) + 1e-5)], 1).contiguous()   # what the producer's epilogue emits
+    return x, st
+
+
+def _deinterleave(v):
+    """undo weights.geglu_interleave on the last axis: [.., 32-blocks of (16 value | 16 gate)] -> (value [.., 4C], gate [.., 4C])"""
+    b = v.reshape(*v.shape[:-1], -1, 2, 16)
+    return b[..., 0, :].reshape(*v.shape[:-1], -1), b[..., 1, :].reshape(*v.shape[:-1], -1)
+
+
+def _reference(x, st, P):
+    """float64 on the bf16 operands: the fold exactly as sdv_hip.h states it, the hidden activations rounded to bf16 once (as both
+    launch forms do), one rounding at the end left to the comparison"""
+    x64, m64, r64 = x.double(), st[:, :1].double(), st[:, 1:].double()
+    w1 = P["w1p"].double()
+    pre = (x64 @ w1.T - m64 * P["s1"].double()[None]) * r64 + P["t1"].double()[None]
+    mag1 = (x64.abs() @ w1.abs().T + m64.abs() * P["s1"].double().abs()[None]) * r64 + P["t1"].double().abs()[None]
+    v, gt = _deinterleave(pre)
+    hid = (v * F.gelu(gt)).to(BF16).double()
+    w2 = P["w2"].double()
+    ref = x64 + hid @ w2.T + P["b2"].double()[None]
+    mag2 = x64.abs() + hid.abs() @ w2.abs().T + P["b2"].double().abs()[None]
+    return ref, mag2, hid, float((mag1.max()))
+
+
+@pytest.mark.parametrize("M", [128, 1000, 4096 * 9 + 77, 4096 * 40])
+def test_ffn_geglu_is_deterministic_and_elementwise_bounded(hip, dev, M):
+    """Every element of the fused launch against float64 within half a bf16 ulp of the result (the one rounding it performs) +
+    1e-5 of the magnitudes summed (fp32 accumulation) + what a hidden activation that rounded the other way can move it by (the
+    kernel's fp32 pre-activations differ from float64 in the last bits, so a few of the 1280 bf16 hidden values per row land on the
+    neighbouring bf16: at most 4 such flips of the largest term are allowed for).  Four launches must agree bit for bit: one wave per
+    SIMD walks panels with its weight stream running ahead across panel boundaries - a slab read before it landed would show here."""
+    P = _weights(dev)
+    x, st = _rows(M, dev, 7 + M)
+    outs = [hip.ffn_geglu(x, st, P["w1p"], P["w1x"], P["w2p"], P["b2"]) for _ in range(4)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16)), "repeated launches differ"
+    worst = 0.0
+    for lo in range(0, M, 32768):            # (float64 in slabs: the 163 840-row case would need 3 GB at once)
+        sl = slice(lo, min(M, lo + 32768))
+        ref, mag2, hid, _ = _reference(x[sl], st[sl], P)
+        ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+        hid_ulp = torch.exp2(torch.floor(torch.log2(hid.abs().clamp_min(1e-30))) - 7)
+        flip = 4.0 * (hid_ulp * 1.0).max(1, keepdim=True).values * P["w2"].double().abs().max(1).values[None]
+        ratio = (outs[0][sl].double() - ref).abs() / (0.5 * ulp * (1 + 1e-3) + 1e-5 * mag2 + flip)
+        worst = max(worst, float(ratio.max()))
+        assert bool(torch.isfinite(outs[0][sl].float()).all())
+    report(f"fused GEGLU feed-forward, M={M}: 4 launches bit-identical, worst element at {worst:.3f} of (half ulp + 1e-5 magnitudes + hidden flips)")
+    assert worst <= 1.0
+
+
+def test_ffn_geglu_agrees_with_the_two_launch_form(hip, dev):
+    """ff.net.0 with the GEGLU epilogue + LayerNorm fold (sdv_gemm_bf16 epi 1, ln_side 1), then ff.net.2 + residual: the same
+    roundings in the same places, so the two forms may differ by the fp32 summation order only - rarely, and by one bf16 ulp."""
+    M = 4096 * 6 + 5
+    P = _weights(dev, seed=3)
+    x, st = _rows(M, dev, 99)
+    a = hip.ffn_geglu(x, st, P["w1p"], P["w1x"], P["w2p"], P["b2"])
+    g = hip.linear(x, P["w1p"], P["t1"], epi=1, ln=(st, P["s1"]))
+    b = hip.linear(g, P["w2"], P["b2"], residual=x)
+    torch.cuda.synchronize()
+    differ = float((a != b).float().mean())
+    # (ulp at the larger of the two values, floored at 2^-4: an output that cancels to ~0 is the difference of O(1) terms)
+    ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(a.float().abs(), b.float().abs()).clamp_min(2.0 ** -4))) - 7)
+    worst = float(((a.float() - b.float()).abs() / ulp).max())
+    report(f"fused vs two-launch feed-forward: {100 * differ:.3f} % of the elements differ, by at most {worst:.2f} bf16 ulp")
+    assert differ < 0.01 and worst <= 2.0
+
+
+def test_ffn_geglu_common_mode_does_not_leak(hip, dev):
+    """The fold terms ride in the matrix product as three-way bf16 splits: a row that is a constant (LayerNorm of it = beta) must
+    come out as x + b2 + W2 GEGLU(W1 beta + b1) whatever the constant - the - mean s term has to cancel x W'^T to fp32 accuracy."""
+    P = _weights(dev, seed=5)
+    vals = torch.tensor([0.0, 1.0, -7.5, 100.0, 3e-3], device=dev)
+    x = vals[:, None].expand(5, C).to(BF16).contiguous()
+    xf = x.float()
+    st = torch.stack([xf.mean(1), torch.rsqrt(xf.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    out = hip.ffn_geglu(x, st, P["w1p"], P["w1x"], P["w2p"], P["b2"])
+    v, gt = _deinterleave(P["t1"].double()[None])
+    expect = (v * F.gelu(gt)).to(BF16).double() @ P["w2"].double().T + P["b2"].double()[None]      # the same for every row
+    got = out.double() - x.double()
+    tol = 2.0 ** -7 * (x.double().abs() + expect.abs()) + 2e-3
+    assert bool(((got - expect).abs() <= tol).all()), float(((got - expect).abs() / tol).max())

@@ -21,7 +21,7 @@ def test_c_abi_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libsdv_hip.so does not export {name}"
     assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip.load().sdv_abi_version() == hip.ABI_VERSION == 10
+    assert hip.load().sdv_abi_version() == hip.ABI_VERSION == 11
 
 
 def test_gemm_args_struct_matches_header(hip):
@@ -60,6 +60,16 @@ def test_argument_validation_without_gpu(hip):
     assert lib.sdv_gemm_bf16(ctypes.byref(a), None) == -1 and b"bad tile" in lib.sdv_last_error()
     a.tile, a.ln_side, a.ln_stats, a.ln_s = 0, 2, 16, 16       # the column-side LayerNorm fold of ABI 9
     assert lib.sdv_gemm_bf16(ctypes.byref(a), None) == -1 and b"ln_side" in lib.sdv_last_error()
+
+
+def test_ffn_argument_validation_without_gpu(hip):
+    """sdv_ffn_geglu_bf16 rejects what it was not built for before it touches the device (C != 320, odd leading dimensions, nulls)"""
+    lib = hip.load()
+    ok = [16, 16, 4096, 320, 320, 16, 16, 16, 16, 16, 320, None]
+    for pos, bad, word in ((3, 640, b"C = 320"), (4, 324, b"ldx"), (0, None, b"null"), (10, 100, b"ldo"), (2, 0, b"bad M")):
+        a = list(ok)
+        a[pos] = bad
+        assert lib.sdv_ffn_geglu_bf16(*a) == -1 and word in lib.sdv_last_error(), (pos, lib.sdv_last_error())
 
 
 def test_split_k_planning_without_gpu(hip):
