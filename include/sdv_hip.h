@@ -178,6 +178,23 @@ int sdv_rowstats_finalize(const float* partials, int64_t rows, int32_t slots, in
 int sdv_ffn_geglu_bf16(const sdv_bf16* X, const float* ln_stats, int64_t M, int32_t C, int32_t ldx, const sdv_bf16* W1, const sdv_bf16* W1x,
                        const sdv_bf16* W2p, const float* bias2, sdv_bf16* out, int32_t ldo, void* stream);
 
+/* The (M, 320, 320) / (M, 960, 320) projections of the C = 320 transformer blocks on the same panel skeleton (csrc/sdv_ffn.hip):
+ *     out[m][n] = bf16( alpha[n / 320] * rstd_m * ( X[m] . W[n] - mean_m * s_n + t_n / rstd_m ) )        R == NULL
+ *     out[m][n] = bf16( X[m] . W[n] + t_n + R[m][n] )                                                    R != NULL (N = 320, no ln_stats / alpha)
+ * Replaces proj_in, attn1.to_q/k/v (one fused N = 960 projection), attn1.to_out, attn2.to_q and attn2.to_out of Transformer2DModel /
+ * BasicTransformerBlock inside unet(...) (stable_diffusion_pipeline.py:418) at the 64 x 64 level, which sdv_gemm_bf16's 256 x 320 tile
+ * ran at 40 - 58 % of the achievable HBM rate.
+ *   X        [M][ldx] bf16 (320 columns used);  W [N][320] bf16 (gamma-folded where a LayerNorm feeds the layer);  N = 320 or 960
+ *   Wx       [N][16] bf16: the fold columns of (s, t) exactly as sdv_ffn_geglu_bf16's W1x - a plain bias is (s = 0, t = bias)
+ *   ln_stats [M][2] fp32 (mean, rstd) of the rows of X, or NULL (mean 0, rstd 1: a plain biased projection)
+ *   alpha    [N / 320] fp32 or NULL: one factor per block of 320 output columns (the Q third of the fused projection carries the
+ *            softmax scale * log2 e: sdv_attention_bf16 q_prescaled)
+ *   R        [M][ldr] bf16 residual or NULL;  out [M][ldo] bf16
+ *   stats_out [M][2] fp32 or NULL (N = 320): (mean, rstd = rsqrt(var + eps)) of the STORED rows - what the next LayerNorm fold
+ *            (ln_stats of a later call, sdv_gemm_args.ln_stats) consumes; no partial sums, no sdv_rowstats_finalize launch */
+int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
+                       const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Flash-style attention, softmax(Q K^T * scale) V, never materialising the score matrix.
  * Replaces CrossAttention.forward inside the UNet (self: Lk = Lq; cross: Lk = 77).

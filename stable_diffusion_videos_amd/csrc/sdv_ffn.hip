@@ -47,6 +47,7 @@ constexpr int B2_OFF = RING_B_OFF + 2 * SLOT_B;
 constexpr int FFN_LDS = B2_OFF + FC * 4;
 static_assert(FFN_LDS <= 160 * 1024, "rings + vectors must fit the 160 KiB LDS");
 
+SDV_DEVICE bf16x8_t kZ16x8() { return bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
 constexpr f32x16_t kZ16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 struct ffn_args {
@@ -373,6 +374,358 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const ffn_args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stream runs a few slabs ahead: nothing may land in a released LDS)
 }
 
+
+// =====================================================================================================================================
+// out[M][N] = LayerNorm-folded / biased projection of a C = 320 activation, N = 320 (proj_in, attn.to_out, attn2.to_q) or 960 (the fused
+// [Q | K | V] projection), on the same panel skeleton: the (M, 320, 320) projections of the 64 x 64 level are HBM-streaming kernels
+// (107 FLOP per byte) that the 256 x 320 igemm tile ran at 40 - 58 % of the achievable HBM rate - each tile re-staged its 205 KB of
+// weights next to 164 KB of activations and kept neither stream going through its epilogue.  Here a wave keeps its 32 tokens' x rows
+// as B fragments, the weights stream through a 5-slot LDS ring (the same [160 x 64] half slabs as ff.net.2's above) in one fixed order
+// that never drains, bias and LayerNorm fold ride in the fold k-step (a plain bias is the fold with mean 0, rstd 1), the residual is the
+// accumulators' initial value, and the LayerNorm statistics of the stored rows - a whole row lives in one wave - leave as (mean, rstd),
+// no partial sums and no finalize launch.  The x rows of the NEXT panel are requested k-slab by k-slab as this panel's last use of
+// each passes.
+struct lin_args {
+    const uint16_t* X;
+    const uint16_t* W;
+    const uint16_t* Wx;
+    const float* ln_stats;
+    const float* alpha;
+    const uint16_t* R;
+    uint16_t* out;
+    float* stats_out;
+    long long M;
+    int ldx, ldr, ldo;
+    float eps;
+};
+
+constexpr int LFOLD_BYTES = 384 * 32;                    // 12 pieces: the block's 320 rows of fold columns + padding to 3 pieces per wave
+constexpr int LIN_FOLD_OFF = 5 * SLOT_B;
+constexpr int LIN_STAGE_OFF = LIN_FOLD_OFF + LFOLD_BYTES;  // three 16 KiB slots: k slabs of the NEXT panel's x rows on their way into registers
+constexpr int LIN_LDS = LIN_STAGE_OFF + 3 * 16384;
+static_assert(LIN_LDS <= 160 * 1024, "ring + fold columns + x staging must fit the 160 KiB LDS");
+
+template <int NB, bool RES>
+__global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int npanels = (int)((p.M + 127) >> 7);
+
+    auto swz = [](int r) { return (r >> 1) & 7; };
+    const int rg = lane >> 3, pc = lane & 7;
+    unsigned voW[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = (wave + 4 * i) * 8 + rg;
+        voW[i] = (unsigned)(r * (FC * 2) + ((pc ^ swz(r)) << 4));
+    }
+    unsigned voF[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) voF[i] = (unsigned)(((wave + 4 * i) * 32 + (lane >> 1)) * 32 + (lane & 1) * 16);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, NB * FC * FC * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wx, 0, NB * FC * 32, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // piece i of half slab (block blk, k slab ks, half hf) -> ring slot `slot`
+    auto pieceW = [&](auto SLOT, int blk, auto KS, auto HF, auto I) __attribute__((always_inline)) {
+        constexpr int slot = decltype(SLOT)::value, ks = decltype(KS)::value, hf = decltype(HF)::value, i = decltype(I)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + slot * SLOT_B + (wave + 4 * i) * 1024), 16, (int)voW[i],
+                                                 (blk * FC + hf * 160) * (FC * 2) + ks * 128, 0, 0);
+    };
+    auto pieceF = [&](int blk, auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsF, (lds_ptr)(smem + LIN_FOLD_OFF + (wave + 4 * i) * 1024), 16, (int)voF[i], blk * FC * 32, 0, 0);
+    };
+    int fo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = l31 * 128 + (((2 * kk + lhi) ^ swz(l31)) << 4);
+    const int fof = l31 * 32 + lhi * 16;
+    // fragment i (= kk * 5 + t) of the half slab in ring slot SLOT; SLOT 5 = the fold columns (fragment i = tile i)
+    auto frag = [&](auto SLOT, auto I) __attribute__((always_inline)) -> bf16x8_t {
+        constexpr int slot = decltype(SLOT)::value, i = decltype(I)::value;
+        if constexpr (slot == 5) return *(const bf16x8_t*)(smem + LIN_FOLD_OFF + i * 1024 + fof);
+        else return *(const bf16x8_t*)(smem + slot * SLOT_B + (i % 5) * 4096 + fo[(i / 5) & 3]);
+    };
+
+    bf16x8_t xf[21];
+    bf16x8_t rf[RES ? 20 : 1];
+    float rs = 1.f, nrs = 1.f;
+    float2 nst = make_float2(0.f, 1.f);
+    float alf[NB];                   // (read ONCE: a load inside the walk is a vmcnt(0) wait in front of its first use - the stream drains)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) alf[b] = p.alpha ? p.alpha[b] : 1.f;
+    f32x16_t acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = kZ16;
+    auto split3 = [](float x, unsigned& h, unsigned& m, unsigned& l) {
+        h = pack_bf16x2(x, 0.f) & 0xffffu;
+        const float r1 = x - __uint_as_float(h << 16);
+        m = pack_bf16x2(r1, 0.f) & 0xffffu;
+        l = pack_bf16x2(r1 - __uint_as_float(m << 16), 0.f) & 0xffffu;
+    };
+    auto tok_of = [&](int panel) {
+        long long tok = (long long)panel * 128 + wave * 32 + l31;
+        return tok < p.M ? tok : p.M - 1;
+    };
+    // The x rows reach the registers through LDS: loaded straight in the fragment layout every instruction touches 32 rows x 32 bytes,
+    // and that shape streams from HBM at 3 - 5 bytes per clock and CU (profiles/round4_ldsdma_fill.txt) - a panel's 80 KB took as long
+    // as the whole panel.  stage_x: this wave's 32 rows of k slab ks as four LDS-DMA pieces of 8 rows x 128 bytes (whole lines, the
+    // weight slabs' swizzled image) into staging slot ks % 3; read_x: the four fragments out of it, once a vmcnt window has closed
+    // behind the pieces (no barrier: a wave reads only rows it fetched itself).
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0x7ffffff0, 0x00020000);
+    auto stage_x = [&](int panel, auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            long long row = (long long)panel * 128 + wave * 32 + 8 * i + rg;
+            row = row < p.M ? row : p.M - 1;
+            const int vo = (int)(row * p.ldx * 2) + ((pc ^ swz(8 * i + rg)) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(smem + LIN_STAGE_OFF + (ks % 3) * 16384 + wave * 4096 + i * 1024), 16, vo, ks * 128, 0, 0);
+        });
+    };
+    auto read_x = [&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xf[4 * ks + kk] = *(const bf16x8_t*)(smem + LIN_STAGE_OFF + (ks % 3) * 16384 + wave * 4096 + fo[kk]);
+    };
+    // ks 6: the statistics of the rows are REQUESTED (early); ks 5: they are split into the fold k-step's token side (late)
+    auto load_x = [&](int panel, auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        static_assert(ks >= 5, "k slabs 0 .. 4 go through stage_x / read_x");
+        const long long tok = tok_of(panel);
+        if constexpr (ks == 6) {      // (the statistics are REQUESTED early - ks 6 - and split into the fold fragment late - ks 5)
+            nst = make_float2(0.f, 1.f);
+            if (p.ln_stats) nst = *(const float2*)(p.ln_stats + 2 * tok);
+        } else {
+            const float mean = nst.x, rstd = nst.y;
+            nrs = rstd;
+            unsigned mh, mm, ml, rh, rm, rl;
+            split3(-mean, mh, mm, ml);
+            split3(1.0f / rstd, rh, rm, rl);
+            const u32x4_t lo = u32x4_t{mh | (mm << 16), mh | (ml << 16), mh | (mm << 16), rh | (rm << 16)};
+            const u32x4_t hi = u32x4_t{rh | (rl << 16), rh | (rm << 16), 0u, 0u};
+            xf[20] = __builtin_bit_cast(bf16x8_t, lhi ? hi : lo);
+        }
+    };
+    auto load_r = [&](int panel) __attribute__((always_inline)) {
+        if constexpr (RES) {
+            const uint16_t* row = p.R + tok_of(panel) * p.ldr + 8 * lhi;
+#pragma unroll
+            for (int s = 0; s < 20; ++s) rf[s] = *(const bf16x8_t*)(row + 16 * s);
+        }
+    };
+    // acc tiles [T0, T1) <- residual rows in the accumulator layout (one register-pair exchange between a token's two lanes)
+    auto init_acc = [&](auto T0, auto T1) __attribute__((always_inline)) {
+        if constexpr (RES) {
+            static_for<decltype(T0)::value, decltype(T1)::value>([&](auto TT) {
+                constexpr int t = decltype(TT)::value;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const u32x4_t d = __builtin_bit_cast(u32x4_t, rf[2 * t + h2]);
+                    const auto r02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                    const auto r13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const int q = 2 * h2 + o;
+                        const unsigned w0 = r02[o], w1 = r13[o];
+                        acc[t][4 * q + 0] = __uint_as_float(w0 << 16);
+                        acc[t][4 * q + 1] = __uint_as_float(w0 & 0xffff0000u);
+                        acc[t][4 * q + 2] = __uint_as_float(w1 << 16);
+                        acc[t][4 * q + 3] = __uint_as_float(w1 & 0xffff0000u);
+                    }
+                }
+            });
+        }
+    };
+    // block blk of panel `panel`: scale, round, store; (sum, sumsq) of the stored values into s1 / s2
+    float s1 = 0.f, s2 = 0.f;
+    auto store_block = [&](int panel, int blk, float scale) __attribute__((always_inline)) {
+        // buffer stores through a descriptor that ends with this wave's last live row: rows past M drop out in the range check, and
+        // EVERY wave issues all 20 stores of a block whatever M is - the counted vmcnt waits of the steps behind rely on that
+        const long long row0 = (long long)panel * 128 + wave * 32;
+        const long long left = p.M - row0;
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (left > 0 ? row0 : 0) * p.ldo), 0,
+                                                                              left > 0 ? (int)((left < 32 ? left : 32) * p.ldo * 2) : 0, 0x00020000);
+        const int vo = (l31 * p.ldo + blk * FC + 8 * lhi) * 2;
+        const unsigned ones = 0x3f803f80u;
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = RES ? acc[t][8 * qp + e] : acc[t][8 * qp + e] * scale;
+                const unsigned a0 = pack_bf16x2(v[0], v[1]), a1 = pack_bf16x2(v[2], v[3]);
+                const unsigned b0 = pack_bf16x2(v[4], v[5]), b1 = pack_bf16x2(v[6], v[7]);
+                if (p.stats_out) {
+                    asm volatile("v_dot2c_f32_bf16 %0, %2, %6\n\tv_dot2c_f32_bf16 %1, %2, %2\n\tv_dot2c_f32_bf16 %0, %3, %6\n\tv_dot2c_f32_bf16 %1, %3, %3\n\t"
+                                 "v_dot2c_f32_bf16 %0, %4, %6\n\tv_dot2c_f32_bf16 %1, %4, %4\n\tv_dot2c_f32_bf16 %0, %5, %6\n\tv_dot2c_f32_bf16 %1, %5, %5\n\ts_nop 2"
+                                 : "+v"(s1), "+v"(s2)
+                                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(ones));
+                }
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                const u32x4_t o = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+#if defined(SDV_LIN_NOSTORE)     // TIMING-ONLY: one store per block instead of 20 (the values stay live through it)
+                if (t == 9 && qp == 1) __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, vo + (32 * t + 16 * qp) * 2, 0, 0);
+                else asm volatile("" ::"v"(o));
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, vo + (32 * t + 16 * qp) * 2, 0, 0);
+#endif
+            }
+    };
+
+    // ---- one step = one half slab: J = its position in the block's 10 (slot J % 5, k slab J / 2, rows half J % 2); J = 10: the fold
+    // k-step (10 MFMAs, one per tile).  The barrier of step J certifies the slab of step J + 1; the slot of step J - 1 is refilled
+    // with the slab five steps after it.  `blk`: the block being computed, `nblk`: the block that follows it in the stream.
+    // vmcnt bookkeeping.  The counter is IN ORDER over every vector-memory operation of the wave - the weight pieces, the x / residual
+    // loads of the next panel (HBM latency) and the stores - so a wait for a weight slab also waits for whatever was issued before
+    // it, and a window that is too small makes the weight stream inherit the HBM latency of the activation loads (the first form of
+    // this kernel: 100 clocks per MFMA).  Hence EVERY operation is issued unconditionally (clamped rows, range-checked stores): the
+    // sequence is static, and the window of a step is the exact number of operations issued behind the slab it needs.
+    //   ops of step s behind its 5 weight pieces: step 0: + 3 fold pieces (+ 20 residual loads of the next panel); odd steps of a
+    //   panel's last block: + 4 x loads; the fold step: + 20 stores
+#ifndef SDV_LIN_AH
+#define SDV_LIN_AH 3
+#endif
+    constexpr int AH = SDV_LIN_AH;
+    bf16x8_t wq[AH];
+    auto step = [&](auto JJ, auto LASTB, auto PREVLAST, auto FIRSTB, int blk, int nblk, int xnext) __attribute__((always_inline)) {
+        constexpr int J = decltype(JJ)::value;
+        constexpr bool lastb = decltype(LASTB)::value != 0, prevlast = decltype(PREVLAST)::value != 0;
+        constexpr auto tail_ops = [](int s, bool last) constexpr {
+            int nn = 0;
+            if (s == 0) nn += 3 + ((RES && last) ? 20 : 0);
+            if (last && s < 10 && (s & 1)) nn += 4;
+            if (s == 10) nn += 20;
+            return nn;
+        };
+        constexpr auto window = [tail_ops](int j, bool last, bool plast) constexpr {
+            const int need = j < 10 ? j + 1 : 11;                 // stream position (this block's steps 0 .. 9; 11 = the next block's step 0) of the slab needed
+            const int is = (need == 11 ? 10 : need) - 4;          // step that issued it (relative to this block; < 0: the previous block's step is + 11)
+            int nn = 0;
+            for (int q = is; q < j; ++q) {
+                const bool lq = q < 0 ? plast : last;
+                const int sq = q < 0 ? q + 11 : q;
+                nn += (q == is ? 0 : (sq < 10 ? 5 : 0)) + tail_ops(sq, lq);
+            }
+            return nn;
+        };
+        constexpr int n = J < 10 ? 20 : 10, slot = J < 10 ? J % 5 : 5, ks = J / 2, hf = J % 2;
+        constexpr int nslot = J < 9 ? (J + 1) % 5 : (J == 9 ? 5 : 0);                 // where the NEXT step's fragments are
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int VM0 = window(J, lastb, prevlast);
+        static_assert(VM0 >= 10 && VM0 <= 63, "vmcnt window");
+#ifdef SDV_LIN_WHATIF      // TIMING-ONLY: windows wider than what was issued (weights may be read before they land)
+        constexpr int VM = VM0 + SDV_LIN_WHATIF > 63 ? 63 : VM0 + SDV_LIN_WHATIF;
+#else
+        constexpr int VM = VM0;
+#endif
+        SDV_VMCNT(VM);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the next panel's x rows: k slab ks was staged behind step 2 ks + 1 of the panel's last block; the first window that has
+        // closed behind it is the one of step 2 ks + 5 - steps 5 / 7 / 9 of that block, steps 1 / 3 of the next panel's first block
+        if constexpr (lastb && (J == 5 || J == 7 || J == 9)) read_x(ic<(J - 5) / 2>{});
+        if constexpr (decltype(FIRSTB)::value != 0 && (J == 1 || J == 3)) read_x(ic<3 + (J - 1) / 2>{});
+        bf16x8_t w[AH + 1], nw[AH];
+#pragma unroll
+        for (int a = 0; a < AH; ++a) w[a] = wq[a];
+        static_for<0, n>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i + AH < n) w[(i + AH) % (AH + 1)] = frag(ic<slot>{}, ic<i + AH>{});
+            else nw[i + AH - n] = frag(ic<nslot>{}, ic<i + AH - n>{});
+            // refills: steps 1 .. 9 refill the slot of step J - 1 with that step's successor five steps on (J + 4: this block's
+            // for J + 4 < 10, else the next block's); step 0 refills step 9's slot; the fold step refills nothing, step 0 of the next
+            // block re-fetches the fold columns behind its own refill
+#if defined(SDV_LIN_NODMA)       // TIMING-ONLY: no weight refills
+            if constexpr (false) {
+#else
+            if constexpr (J < 10 && i < 5) {
+#endif
+                constexpr int pj = (J + 9) % 10, tj = (pj + 5) % 10;              // step whose slot is free / step whose slab goes there
+                // J >= 1: target step tj = J + 4 belongs to this block if J + 4 < 10, else to the next; J == 0: tj = 4 of THIS block
+                pieceW(ic<pj % 5>{}, (J >= 1 && J + 4 >= 10) ? nblk : blk, ic<tj / 2>{}, ic<tj % 2>{}, I);
+            }
+            if constexpr (J == 0 && i >= 5 && i < 8) pieceF(blk, ic<i - 5>{});
+            if constexpr (J < 10)
+                acc[5 * hf + i % 5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i % (AH + 1)], xf[4 * ks + i / 5],
+                                                                              (!RES && ks == 0 && i / 5 == 0) ? kZ16 : acc[5 * hf + i % 5], 0, 0, 0);
+            else
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i % (AH + 1)], xf[20], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int a = 0; a < AH; ++a) wq[a] = nw[a];
+        // the x rows of the next panel, k slab by k slab, once this panel's last block is through with them
+        if constexpr (lastb && J < 10 && hf == 1) stage_x(xnext, ic<ks>{});
+        if constexpr (lastb && J == 1) load_x(xnext, ic<6>{});
+        if constexpr (lastb && J == 10) load_x(xnext, ic<5>{});
+    };
+
+    // ---- the walk ------------------------------------------------------------------------------------------------------------
+    int cur = blockIdx.x;
+    if (cur >= npanels) return;
+    load_x(cur, ic<6>{});
+    static_for<0, 3>([&](auto KS) { stage_x(cur, KS); });          // the first panel's x rows, through the three staging slots in two rounds
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<0, 3>([&](auto KS) { read_x(KS); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<3, 5>([&](auto KS) { stage_x(cur, KS); });          // (slabs 3 / 4 stay in their slots: the first panel's steps 1 / 3 read them again)
+    load_x(cur, ic<5>{});
+    load_r(cur);
+    // fill the ring: the first five half slabs of block 0 + its fold columns
+    static_for<0, 5>([&](auto S) { static_for<0, 5>([&](auto I) { pieceW(S, 0, ic<decltype(S)::value / 2>{}, ic<decltype(S)::value % 2>{}, I); }); });
+    static_for<0, 3>([&](auto I) { pieceF(0, I); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < AH; ++a) wq[a] = kZ16x8();
+    static_for<0, AH>([&](auto A) { wq[decltype(A)::value] = frag(ic<0>{}, A); });
+    for (;;) {
+        const int nxt = cur + (int)gridDim.x;
+        rs = nrs;
+        s1 = s2 = 0.f;
+        const int xn = nxt < npanels ? nxt : cur;     // (past the end: the loads are issued all the same - see the vmcnt bookkeeping - and dropped)
+        static_for<0, NB>([&](auto BLK) {
+            constexpr int blk = decltype(BLK)::value;
+            constexpr int nblk = blk + 1 < NB ? blk + 1 : 0;
+            using LB = ic<blk == NB - 1>;
+            using PL = ic<(NB == 1 || blk == 0)>;
+            using FB = ic<blk == 0>;
+            if constexpr (RES) init_acc(ic<0>{}, ic<5>{});
+            step(ic<0>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            if constexpr (RES) {
+                init_acc(ic<5>{}, ic<10>{});
+                load_r(xn);                       // (the residual registers are free again: the next panel's rows)
+            }
+            step(ic<1>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<2>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<3>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<4>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<5>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<6>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<7>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<8>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<9>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            step(ic<10>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            store_block(cur, blk, rs * alf[blk]);
+        });
+        if (p.stats_out) {
+            const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+            const float mean = t1 * (1.0f / (NB * FC));
+            const float var = fmaxf(t2 * (1.0f / (NB * FC)) - mean * mean, 0.f);
+            const long long tok = (long long)cur * 128 + wave * 32 + l31;
+            if (lhi == 0 && tok < p.M) *(float2*)(p.stats_out + 2 * tok) = make_float2(mean, rsqrtf(var + p.eps));
+        }
+        if (nxt >= npanels) break;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 // C ABI: sdv_hip.h
@@ -401,5 +754,45 @@ extern "C" int sdv_ffn_geglu_bf16(const sdv_bf16* X, const float* ln_stats, int6
     ffn_args a{X, W1, W1x, W2p, bias2, ln_stats, out, M, ldx, ldo};
     hipLaunchKernelGGL(ffn_geglu_kernel, dim3((unsigned)(npanels < cus[dev] ? npanels : cus[dev])), dim3(256), FFN_LDS, (hipStream_t)stream, a);
     SDV_CHECK_LAUNCH("sdv_ffn_geglu_bf16");
+    return SDV_OK;
+}
+
+extern "C" int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
+                                  const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps,
+                                  void* stream) {
+    SDV_REQUIRE(X && W && Wx && out, "sdv_linear320_bf16: null pointer");
+    SDV_REQUIRE(N == FC || N == 3 * FC, "sdv_linear320_bf16: N must be 320 or 960, got %d", N);
+    SDV_REQUIRE(M > 0 && M < (1LL << 31) - 128, "sdv_linear320_bf16: bad M");
+    SDV_REQUIRE(ldx >= FC && ldo >= N && ldx % 8 == 0 && ldo % 8 == 0 && (!R || (ldr >= FC && ldr % 8 == 0)), "sdv_linear320_bf16: leading dimensions must be multiples of 8 and cover the rows");
+    SDV_REQUIRE(!R || (N == FC && !ln_stats && !alpha), "sdv_linear320_bf16: a residual goes with N = 320 and no fold / alpha (it is the accumulators' initial value)");
+    SDV_REQUIRE(!stats_out || N == FC, "sdv_linear320_bf16: row statistics exist for N = 320");
+    SDV_REQUIRE(((((uintptr_t)X) | ((uintptr_t)out) | ((uintptr_t)W) | ((uintptr_t)Wx) | ((uintptr_t)R)) & 15) == 0 &&
+                    ((((uintptr_t)ln_stats) | ((uintptr_t)stats_out)) & 7) == 0,
+                "sdv_linear320_bf16: unaligned pointers");
+    static int cus[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    auto launch = [&](auto kern) {
+        static unsigned long long attr_set = 0;
+        if (!(attr_set & (1ull << dev))) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_LDS);
+            attr_set |= 1ull << dev;
+        }
+        const int npanels = (int)((M + 127) >> 7);
+        lin_args a{X, W, Wx, ln_stats, alpha, R, out, stats_out, M, ldx, ldr, ldo, eps};
+        hipLaunchKernelGGL(kern, dim3((unsigned)(npanels < cus[dev] ? npanels : cus[dev])), dim3(256), LIN_LDS, (hipStream_t)stream, a);
+    };
+    if (N == FC) {
+        if (R) launch(panel_linear_kernel<1, true>);
+        else launch(panel_linear_kernel<1, false>);
+    } else {
+        launch(panel_linear_kernel<3, false>);
+    }
+    SDV_CHECK_LAUNCH("sdv_linear320_bf16");
     return SDV_OK;
 }

@@ -187,6 +187,19 @@ class _Transformer:
         # C = 320 (the 64 x 64 level): norm3 -> ff.net.0 -> GEGLU -> ff.net.2 -> + residual is ONE launch (sdv_ffn_geglu_bf16) - the
         # hidden activations never leave the registers; the LayerNorm fold's per-column terms ride in the matrix product (w1x)
         self.ffn_fused = hip.FFN_FUSED and self.C == 320
+        # C = 320: proj_in, the fused Q / K / V projection, attn1.to_out, attn2.to_q and attn2.to_out run on the panel kernel
+        # (sdv_linear320_bf16): bias / LayerNorm fold in the fold k-step (wx), the row statistics leave as (mean, rstd) directly
+        self.lin320 = hip.LINEAR320 and self.C == 320
+        if self.lin320:
+            z = torch.zeros(self.C, dtype=torch.float32, device=device)
+            self.wx_in = ffn_fold_columns(z, self.b_in)
+            self.wx_o1 = ffn_fold_columns(z, self.bo1)
+            self.wx_o2 = ffn_fold_columns(z, self.bo2)
+            # (the fold columns carry t / alpha: the kernel multiplies the whole bracket by alpha * rstd)
+            self.wx_qkv = ffn_fold_columns(self.sqkv1, torch.cat([tq / qs, tk, tv]))
+            self.al_qkv = torch.tensor([qs, 1.0, 1.0], dtype=torch.float32, device=device)
+            self.wx_q2 = ffn_fold_columns(self.sq2, self.tq2 / qs)
+            self.al_q2 = torch.tensor([qs], dtype=torch.float32, device=device)
         if self.ffn_fused:
             self.w1x = ffn_fold_columns(self.sff1, self.bff1)
             self.w2p = ffn_w2_permute(self.wff2)
@@ -246,26 +259,41 @@ class _Transformer:
         if not self.fold:
             return self._call_unfolded(x, nimg, H, W, shared_prefix, out, ctx_of)
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
-        h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)            # + (mean, rstd) of every token for norm1
+        if self.lin320:
+            h, st1 = hip.linear320(h, self.w_in, self.wx_in, want_stats=True)
+        else:
+            h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)        # + (mean, rstd) of every token for norm1
         _tap(self.name, "tf_in", x=x, out=h, nimg=nb, H=H, W=W)
         h_in = h
         # --- self attention: LN1 lives inside the fused Q / K / V projection ---
         qs = hip.q_prescale(dh)       # softmax scale * log2(e), applied by the Q projections before their single rounding
-        qkv = hip.linear(h, self.wqkv1, self.tqkv1, alpha=qs, alpha_cols=C, ln=(st1, self.sqkv1))   # [Mb, 3C] = [Q * qs | K | V]
+        if self.lin320:
+            qkv = hip.linear320(h, self.wqkv1, self.wx_qkv, ln_stats=st1, alpha=self.al_qkv)          # [Mb, 3C] = [Q * qs | K | V]
+        else:
+            qkv = hip.linear(h, self.wqkv1, self.tqkv1, alpha=qs, alpha_cols=C, ln=(st1, self.sqkv1))
         o = torch.empty((Mb, C), dtype=BF16, device=x.device)
         hip.attention(qkv, qkv, qkv, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C,
                       scale=scale, k_off=C, v_off=2 * C, q_prescaled=True, v_rowmajor=True)
-        h, st2 = hip.linear(o, self.wo1, self.bo1, residual=h, want_stats=True)
+        if self.lin320:
+            h, st2 = hip.linear320(o, self.wo1, self.wx_o1, residual=h, want_stats=True)
+        else:
+            h, st2 = hip.linear(o, self.wo1, self.bo1, residual=h, want_stats=True)
         _tap(self.name, "tf_attn1", x=h_in, out=h, nimg=nb, H=H, W=W)
         h_in = h
         # --- cross attention on the text context (LN2 inside the Q projection) ---
-        q = hip.linear(h, self.wq2, self.tq2, alpha=qs, ln=(st2, self.sq2))
+        if self.lin320:
+            q = hip.linear320(h, self.wq2, self.wx_q2, ln_stats=st2, alpha=self.al_q2)
+        else:
+            q = hip.linear(h, self.wq2, self.tq2, alpha=qs, ln=(st2, self.sq2))
         o2 = torch.empty((M, C), dtype=BF16, device=x.device)
         ctx_k, ctx_vt, Lc = self._context(nimg, ctx_of)
         if not shared_prefix:
             hip.attention(q, ctx_k, ctx_vt, o2, B=nimg, H=heads, Lq=HW, Lk=Lc, dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2],
                           ldo=C, scale=scale, q_prescaled=True)
-            h, st3 = hip.linear(o2, self.wo2, self.bo2, residual=h, want_stats=True)
+            if self.lin320:
+                h, st3 = hip.linear320(o2, self.wo2, self.wx_o2, residual=h, want_stats=True)
+            else:
+                h, st3 = hip.linear(o2, self.wo2, self.bo2, residual=h, want_stats=True)
         else:
             # same queries against the unconditional and the conditional context; the residual stream h is still
             # shared, so the output projection reads it with batch stride 0 and writes both halves

@@ -72,6 +72,17 @@ def test_ffn_argument_validation_without_gpu(hip):
         assert lib.sdv_ffn_geglu_bf16(*a) == -1 and word in lib.sdv_last_error(), (pos, lib.sdv_last_error())
 
 
+def test_linear320_argument_validation_without_gpu(hip):
+    """sdv_linear320_bf16: N is 320 or 960, a residual excludes fold / alpha / N = 960, statistics exist for N = 320 only"""
+    lib = hip.load()
+    ok = dict(X=16, M=4096, ldx=320, W=16, Wx=16, N=320, ln_stats=None, alpha=None, R=None, ldr=0, out=16, ldo=320, stats_out=None, eps=1e-5, stream=None)
+    for change, word in ((dict(N=640), b"320 or 960"), (dict(R=16, ldr=320, ln_stats=16), b"residual"), (dict(N=960, ldo=960, stats_out=16), b"statistics"),
+                         (dict(N=960, ldo=320), b"leading"), (dict(W=None), b"null"), (dict(X=18), b"unaligned")):
+        a = dict(ok)
+        a.update(change)
+        assert lib.sdv_linear320_bf16(*a.values()) == -1 and word in lib.sdv_last_error(), (change, lib.sdv_last_error())
+
+
 def test_split_k_planning_without_gpu(hip):
     """sdv_gemm_split_k is pure host logic (sdv_hip.h "split_k"): the small-batch shapes of the UNet split, everything the second pass
     cannot finish - or that fills the chip by itself - does not.  Shapes: ResBlock conv3x3 1280 -> 1280 at the 8 x 8 level of a 1 / 4 /

@@ -36,6 +36,9 @@ def setup(arch):
 
 def noise(seconds, arch):
     pipe, x2, B, h, step = setup(arch)
+    pipe.unet.forward(x2, 2 * B, h, h, step, cfg_shared=True)
+    torch.cuda.synchronize()
+    print("ready", flush=True)          # (tests/test_contention_gpu.py waits for this line before it starts comparing)
     t0 = time.time()
     while time.time() - t0 < seconds:
         for _ in range(5):
