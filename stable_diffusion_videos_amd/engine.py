@@ -301,8 +301,14 @@ class _Transformer:
                 hip.attention(q, ctx_k[half * nb * Lc:], ctx_vt[half * nb:], o2[half * Mb:], B=nb, H=heads, Lq=HW, Lk=Lc,
                               dh=dh, ldq=C, ldk=C, ldv=ctx_vt.shape[2], ldo=C, scale=scale, q_prescaled=True)
             h2 = torch.empty((M, C), dtype=BF16, device=x.device)
-            st3 = hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
-                           sX=Mb * C, sW=0, sC=Mb * C, sR=0, want_stats=True)
+            if self.lin320:       # (the same kernel, row for row, as the unshared forward runs: the shared prefix stays EXACT)
+                st3 = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+                for half in range(2):
+                    hip.linear320(o2[half * Mb:(half + 1) * Mb], self.wo2, self.wx_o2, residual=h, out=h2[half * Mb:(half + 1) * Mb],
+                                  want_stats=True, stats_out=st3[half * Mb:(half + 1) * Mb])
+            else:
+                st3 = hip.gemm(o2, self.wo2, h2, M=Mb, N=C, K=C, ldx=C, ldw=C, ldc=C, bias=self.bo2, residual=h, ldr=C, batch=2,
+                               sX=Mb * C, sW=0, sC=Mb * C, sR=0, want_stats=True)
             h = h2
         _tap(self.name, "tf_attn2", x=h_in, out=h, nimg=nb, H=H, W=W, shared_prefix=shared_prefix)
         h_in = h

@@ -549,14 +549,14 @@ LINEAR320 = os.environ.get("SDV_LINEAR320", "1") != "0"     # A/B knob: 0 = the 
 
 
 def linear320(x: torch.Tensor, w: torch.Tensor, wx: torch.Tensor, *, ln_stats=None, alpha=None, residual=None, out=None, want_stats: bool = False,
-              eps: float = 1e-5):
+              eps: float = 1e-5, stats_out=None):
     """A C = 320 projection on the panel kernel (``torch.ops.sdv.k_linear320`` -> sdv_linear320_bf16): N = 320 or 960 output
     columns, bias / LayerNorm fold in ``wx`` (``weights.ffn_fold_columns(s, t)``), optional per-320-column ``alpha``, residual and the
     LayerNorm statistics of the stored rows (returned as ``(y, stats [M, 2])`` with ``want_stats``)."""
     M = x.shape[0]
     if out is None:
         out = torch.empty((M, w.shape[0]), dtype=BF16, device=x.device)
-    st = torch.empty((M, 2), dtype=F32, device=x.device) if want_stats else None
+    st = (stats_out if stats_out is not None else torch.empty((M, 2), dtype=F32, device=x.device)) if want_stats else None
     _k_linear320(x, w, wx, ln_stats, alpha, residual, out, st, float(eps))
     return (out, st) if want_stats else out
 

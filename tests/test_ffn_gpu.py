@@ -95,8 +95,9 @@ def test_ffn_geglu_agrees_with_the_two_launch_form(hip, dev):
     b = hip.linear(g, P["w2"], P["b2"], residual=x)
     torch.cuda.synchronize()
     differ = float((a != b).float().mean())
-    # (ulp at the larger of the two values, floored at 2^-4: an output that cancels to ~0 is the difference of O(1) terms)
-    ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(a.float().abs(), b.float().abs()).clamp_min(2.0 ** -4))) - 7)
+    # (ulp at the largest of the two values and the residual they both add: an output that cancels is the difference of larger terms)
+    big = torch.maximum(torch.maximum(a.float().abs(), b.float().abs()), x.float().abs()).clamp_min(2.0 ** -4)
+    ulp = torch.exp2(torch.floor(torch.log2(big)) - 7)
     worst = float(((a.float() - b.float()).abs() / ulp).max())
     report(f"fused vs two-launch feed-forward: {100 * differ:.3f} % of the elements differ, by at most {worst:.2f} bf16 ulp")
     assert differ < 0.01 and worst <= 2.0
