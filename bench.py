@@ -182,6 +182,8 @@ def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
         which run that tile themselves: then every output element sees the same sequence of MFMA k-steps whatever the batch, the
         GroupNorm statistics are split by image size only, attention is per (sample, head), and the frames must be BIT-IDENTICAL.
         (For a small timed batch the comparison would pit the cost model's small tiles against a forced big one - two realisations.)
+    (c) for a timed batch below 64 frames (no forced-tile check applies): the WHOLE batch once more, eagerly, at its own size - the
+        same launches the captured step graph replays, so graph replay vs eager launches must be BIT-IDENTICAL.
     Both recomputations run eagerly (no step graph is captured for them), so (b)'s launches really are the forced tile's."""
     from stable_diffusion_videos_amd import hip
     B = embeds.shape[0]
@@ -199,6 +201,9 @@ def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
         if forced:
             hip.FORCE_TILE = 6
             b = pipe(**kw)["images"]
+        elif not same_batch:
+            kw.update(latents=noise, text_embeddings=embeds)
+            out["max_abs_u8_same_batch_eager"] = int(np.abs(pipe(**kw)["images"].astype(np.int32) - frames_u8.astype(np.int32)).max())
     finally:
         pipe.use_graphs, hip.FORCE_TILE = graphs, prev_tile
     ref = frames_u8[idx].astype(np.int32)
@@ -211,6 +216,7 @@ def parity_check(pipe, embeds, noise, frames_u8, size, inference_steps):
     if b is not None:
         out["max_abs_u8_same_tiles"] = int(np.abs(b.astype(np.int32) - ref).max())
         ok = ok and out["max_abs_u8_same_tiles"] == 0
+    ok = ok and out.get("max_abs_u8_same_batch_eager", 0) == 0
     out["ok"] = bool(ok)
     return out
 
@@ -364,11 +370,11 @@ def profile_fingerprint(path: Path) -> str:
 
 def pmc_profile(batch):
     """Counters of the committed rocprofv3 --pmc passes over one UNet forward at this bench's batch
-    (profiles/round5_pmc_unet_b<batch>.csv, made by tools/pmc_summary.py from `rocprofv3 --pmc ... tools/unet_once.py <batch>`;
+    (profiles/round6_pmc_unet_b<batch>.csv, made by tools/pmc_summary.py from `rocprofv3 --pmc ... tools/unet_once.py <batch>`;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns {kernel: {counter: mean per launch}} - or {} when
     there is no profile for this batch size OR the profile was collected from other kernel sources than this tree's
     (`# csrc=` fingerprint in its first line != csrc_fingerprint()): a replayed number must describe the code that ships."""
-    path = ROOT / "profiles" / f"round5_pmc_unet_b{batch}.csv"
+    path = ROOT / "profiles" / f"round6_pmc_unet_b{batch}.csv"
     pmc_profile.stale = None
     if not path.exists():
         return {}
@@ -414,7 +420,7 @@ def rocprof_conv_average(batch):
     """Average launch duration of the dominant kernel (both bf16 variants of the 256 x 320 conv) in the committed
     `rocprofv3 --kernel-trace --stats` summary of this bench command - only when that summary was collected from this tree's
     kernel sources - and the algorithmic TFLOP/s it implies, next to the live HIP-event figure."""
-    path = ROOT / "profiles" / f"round5_bench_b{batch}_kernel_stats.csv"
+    path = ROOT / "profiles" / f"round6_bench_b{batch}_kernel_stats.csv"
     if not path.exists() or profile_fingerprint(path) != csrc_fingerprint():
         return None
     import csv
@@ -684,8 +690,10 @@ def main():
                 n2 = len(list((Path(tmp) / "w2").rglob("frame*.png")))
                 result["walk_60_frames_warm"] = {"frames": n2, "seconds": round(dt2, 3), "frames_per_sec": round(n2 / dt2, 4),
                                                  "batch_size": 60, "includes": "as walk_60_frames, step graph already captured"}
-                # the PNG-inclusive rate is the WARM walk (the cold one measures the first call's set-up, reported on its own)
-                result["frames_per_sec_incl_png"] = round(n2 / dt2, 4)
+                # the PNG-inclusive rate of the WARM walk (step graph cached) and of the COLD one (a one-shot CLI call, which pays
+                # the first call's buffers + graph capture), under keys that say which
+                result["frames_per_sec_incl_png_warm"] = round(n2 / dt2, 4)
+                result["frames_per_sec_incl_png_cold"] = round(n_png / dt, 4)
                 result["walk_60_frames"]["cold_start_s"] = round(dt - dt2, 3)
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
@@ -712,6 +720,7 @@ def main():
             import gc
             oc = {}
             try:
+                pipe._drop_graphs()          # so that every size's first call really is a cold one (60 was captured by the walk pass)
                 oc["batch_sweep"] = batch_sweep(pipe, size, args.inference_steps)
             except Exception as exc:  # the headline line must still be printed
                 oc["batch_sweep"] = {"error": repr(exc)}

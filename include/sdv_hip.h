@@ -191,9 +191,13 @@ int sdv_ffn_geglu_bf16(const sdv_bf16* X, const float* ln_stats, int64_t M, int3
  *            softmax scale * log2 e: sdv_attention_bf16 q_prescaled)
  *   R        [M][ldr] bf16 residual or NULL;  out [M][ldo] bf16
  *   stats_out [M][2] fp32 or NULL (N = 320): (mean, rstd = rsqrt(var + eps)) of the STORED rows - what the next LayerNorm fold
- *            (ln_stats of a later call, sdv_gemm_args.ln_stats) consumes; no partial sums, no sdv_rowstats_finalize launch */
+ *            (ln_stats of a later call, sdv_gemm_args.ln_stats) consumes; no partial sums, no sdv_rowstats_finalize launch
+ *   Vt       NULL, or (N = 960) [M / hw][320][ldvt] bf16: the LAST block of 320 columns - V of the fused Q K V projection - is stored
+ *            TRANSPOSED per sample of hw tokens (hw % 128 == 0, M % hw == 0, ldvt >= hw), as sdv_attention_bf16 takes it with
+ *            v_rowmajor = 0, and `out` ([M][ldo], ldo >= 640) receives only [Q | K] */
 int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
-                       const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps, void* stream);
+                       const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps,
+                       sdv_bf16* Vt, int32_t ldvt, int32_t hw, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flash-style attention, softmax(Q K^T * scale) V, never materialising the score matrix.

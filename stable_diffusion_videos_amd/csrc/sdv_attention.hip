@@ -28,6 +28,9 @@ constexpr f32x16_t kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 
 #ifndef SDV_ATTN_SLAB64
 #define SDV_ATTN_SLAB64 0
 #endif
+#ifndef SDV_ATTN_PP_DBUF
+#define SDV_ATTN_PP_DBUF 0
+#endif
 constexpr float kDefer = 5.0f;  // log2 units: skip the O rescale while the running max moves by < 2^5
 
 template <int DH, bool VRM = false>
@@ -408,13 +411,13 @@ __global__ __launch_bounds__(NW * 64, (DH == 64 && VRM && !RES) ? 4 : 1) void at
             // hide behind (the softmax here is ~95 VALU per 14 MFMAs - far above what one wave can hide per MFMA):
             //   S0 = K.Q0 | S1 = K.Q1 || max(S0) | { P0 quarter = exp2(S0 quarter); O0 += V.P0 quarter } x 4 | max(S1) |
             //   { P1 quarter = exp2(S1 quarter); O1 += V.P1 quarter } x 4
-            static_assert(QT == 2 && PADM && ONES && !DBUF, "PP: dh = 40 LEAN kernel with two query tiles");
+            static_assert(QT == 2 && PADM && ONES, "PP: dh = 40 LEAN kernel with two query tiles");
             bf16x8_t kfr[2][DKS];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int ks = 0; ks < DKS; ++ks)
-                    kfr[j][ks] = *(const bf16x8_t*)(ldsK + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
+                    kfr[j][ks] = *(const bf16x8_t*)(ldsK + boff + (j * 32 + l31) * KROW + (ks * 16 + lhi * 8) * 2);
             auto qk = [&](int qt, int j) {
                 f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[j][0], qf[qt][0], kZero16, 0, 0, 0);
 #pragma unroll
@@ -457,11 +460,11 @@ __global__ __launch_bounds__(NW * 64, (DH == 64 && VRM && !RES) ? 4 : 1) void at
 #pragma unroll
                 for (int ju = 0; ju < 4; ++ju)
 #pragma unroll
-                    for (int dt = 0; dt < DVT; ++dt) vfr[dt][ju] = vfrag_at(0, dt, ju);
+                    for (int dt = 0; dt < DVT; ++dt) vfr[dt][ju] = vfrag_at(boff, dt, ju);
             }
             auto vfrag = [&](int dt, int ju) __attribute__((always_inline)) {
                 if constexpr (VRM) return vfr[dt][ju];
-                else return vfrag_at(0, dt, ju);
+                else return vfrag_at(boff, dt, ju);
             };
             auto exp_quarter = [&](const f32x16_t& a, int u) {                  // 8 scores -> one B fragment
                 u32x4_t pr;
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(NW * 64, (DH == 64 && VRM && !RES) ? 4 : 1) void at
             if (t == 0 || !__all(mx <= kDefer)) rescale(1, mx, s1a, s1b);
             softmax_pv(1, s1a, s1b);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            if constexpr (DBUF) __syncthreads();   // tile t+1 visible; everyone is done reading tile t's buffer
             continue;
         }
         // ---- S^T = K . Q^T for two 32-key subtiles (each K fragment feeds QT MFMAs) ----
@@ -722,7 +726,10 @@ int launch_attention_q(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt,
         // software-pipelined two-query-tile kernel: dh = 40, full key tiles only, no mask (the 64^2 self-attention; the caller
         // checks).  Two tiles per wave WITHOUT the pipelined body measured -3 % .. +1 % and are not compiled.
         static_assert(DH == 40, "two query tiles per wave exist for dh = 40 only");
-        hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, false, true, 4, false, VRM>), grid, dim3(256), lds, s, Q, K, Vt, O, H, Lq,
+        // (SDV_ATTN_PP_DBUF: two K / V tile buffers, one barrier per key tile instead of two - an A/B switch for tools builds)
+        constexpr bool dbuf = SDV_ATTN_PP_DBUF != 0;
+        constexpr int lds2 = dbuf ? 2 * (Cfg::K_BYTES + Cfg::V_BYTES) : Cfg::LDS_BYTES;
+        hipLaunchKernelGGL((attention_kernel<DH, QT, true, true, dbuf, true, 4, false, VRM>), grid, dim3(256), lds2, s, Q, K, Vt, O, H, Lq,
                            Lk, ldq, ldk, ldv, ldo, sl, flags, B * H);
     } else {
         SDV_ATTN_LAUNCH(true, lean, false);

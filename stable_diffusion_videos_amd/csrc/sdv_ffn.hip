@@ -394,8 +394,9 @@ struct lin_args {
     const uint16_t* R;
     uint16_t* out;
     float* stats_out;
+    uint16_t* Vt;
     long long M;
-    int ldx, ldr, ldo;
+    int ldx, ldr, ldo, ldvt, hw;
     float eps;
 };
 
@@ -539,42 +540,94 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
             });
         }
     };
-    // block blk of panel `panel`: scale, round, store; (sum, sumsq) of the stored values into s1 / s2
+    // block blk of panel `panel`: scale, round, store; (sum, sumsq) of the stored values into s1 / s2.
+    // The values leave through LDS, 64 channels (two tiles) at a time: straight from the accumulator layout a store instruction
+    // writes 32 rows x 32 bytes - quarter lines - and the [tokens, 960] output of the fused Q / K / V projection ran at 3.2 TB/s.
+    // Each wave parks the slice in its 4 KiB of staging slot 2 (free whenever an epilogue runs: k slab 2 of the next panel was read
+    // at step 9, and nothing but the last block of a panel stages) as [32 tokens][128 bytes], 16-byte chunks XOR-swizzled by the row,
+    // and reads it back
+    //   * row-major - 8 lanes per token row: every store instruction writes 8 whole 128-byte lines; or
+    //   * TRANSPOSED (the V third when p.Vt is given) - ds_read_b64_tr_b16 hands lane (token group g, channel i) the 8 tokens
+    //     8 g .. 8 g + 7 of ITS channel: one 16-byte store into V^T[sample][channel][token], 64 contiguous bytes per channel and
+    //     instruction - the layout the self-attention kernel's one-read-per-fragment form wants (sdv_attention_bf16 v_rowmajor = 0).
     float s1 = 0.f, s2 = 0.f;
+    typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) slab_u4;
+    typedef unsigned int __attribute__((ext_vector_type(2), may_alias)) slab_u2;
     auto store_block = [&](int panel, int blk, float scale) __attribute__((always_inline)) {
         // buffer stores through a descriptor that ends with this wave's last live row: rows past M drop out in the range check, and
         // EVERY wave issues all 20 stores of a block whatever M is - the counted vmcnt waits of the steps behind rely on that
         const long long row0 = (long long)panel * 128 + wave * 32;
         const long long left = p.M - row0;
-        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (left > 0 ? row0 : 0) * p.ldo), 0,
-                                                                              left > 0 ? (int)((left < 32 ? left : 32) * p.ldo * 2) : 0, 0x00020000);
-        const int vo = (l31 * p.ldo + blk * FC + 8 * lhi) * 2;
+        const bool tr = p.Vt != nullptr && blk == 2;
+        char* const slab = smem + LIN_STAGE_OFF + 2 * 16384 + wave * 4096;
         const unsigned ones = 0x3f803f80u;
+        __amdgpu_buffer_rsrc_t rs_o;
+        int vo[4];
+        if (!tr) {
+            rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (left > 0 ? row0 : 0) * p.ldo), 0,
+                                                     left > 0 ? (int)((left < 32 ? left : 32) * p.ldo * 2) : 0, 0x00020000);
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+            for (int j = 0; j < 4; ++j) vo[j] = ((8 * j + (lane >> 3)) * p.ldo + blk * FC + 8 * (lane & 7)) * 2;
+        } else {
+            // V^T[sample][channel][token]: this wave's 32 tokens are tokens t0 .. t0 + 31 of sample b (hw % 128 == 0: host)
+            const long long b = row0 / p.hw, t0 = row0 - b * p.hw;
+            rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vt + (b * FC * p.ldvt + t0)), 0, left > 0 ? (int)((FC - 1) * p.ldvt + 32) * 2 : 0, 0x00020000);
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {
-                float v[8];
+            for (int j = 0; j < 4; ++j) vo[j] = ((16 * j + (lane & 15)) * p.ldvt + 8 * (lane >> 4)) * 2;
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = RES ? acc[t][8 * qp + e] : acc[t][8 * qp + e] * scale;
-                const unsigned a0 = pack_bf16x2(v[0], v[1]), a1 = pack_bf16x2(v[2], v[3]);
-                const unsigned b0 = pack_bf16x2(v[4], v[5]), b1 = pack_bf16x2(v[6], v[7]);
-                if (p.stats_out) {
-                    asm volatile("v_dot2c_f32_bf16 %0, %2, %6\n\tv_dot2c_f32_bf16 %1, %2, %2\n\tv_dot2c_f32_bf16 %0, %3, %6\n\tv_dot2c_f32_bf16 %1, %3, %3\n\t"
-                                 "v_dot2c_f32_bf16 %0, %4, %6\n\tv_dot2c_f32_bf16 %1, %4, %4\n\tv_dot2c_f32_bf16 %0, %5, %6\n\tv_dot2c_f32_bf16 %1, %5, %5\n\ts_nop 2"
-                                 : "+v"(s1), "+v"(s2)
-                                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(ones));
+        for (int sl = 0; sl < 5; ++sl) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    const int t = 2 * sl + tt;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = RES ? acc[t][8 * qp + e] : acc[t][8 * qp + e] * scale;
+                    const unsigned a0 = pack_bf16x2(v[0], v[1]), a1 = pack_bf16x2(v[2], v[3]);
+                    const unsigned b0 = pack_bf16x2(v[4], v[5]), b1 = pack_bf16x2(v[6], v[7]);
+                    if (p.stats_out) {
+                        asm volatile("v_dot2c_f32_bf16 %0, %2, %6\n\tv_dot2c_f32_bf16 %1, %2, %2\n\tv_dot2c_f32_bf16 %0, %3, %6\n\tv_dot2c_f32_bf16 %1, %3, %3\n\t"
+                                     "v_dot2c_f32_bf16 %0, %4, %6\n\tv_dot2c_f32_bf16 %1, %4, %4\n\tv_dot2c_f32_bf16 %0, %5, %6\n\tv_dot2c_f32_bf16 %1, %5, %5\n\ts_nop 2"
+                                     : "+v"(s1), "+v"(s2)
+                                     : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(ones));
+                    }
+                    // quads 2 qp / 2 qp + 1 = channels 32 tt + 16 qp + {0, 8} + 4 lhi + {0..3} of the slice: 16-byte chunk 4 tt + 2 qp + o, half lhi
+                    *(slab_u2*)(slab + l31 * 128 + (((4 * tt + 2 * qp) ^ (l31 & 7)) << 4) + lhi * 8) = slab_u2{a0, a1};
+                    *(slab_u2*)(slab + l31 * 128 + (((4 * tt + 2 * qp + 1) ^ (l31 & 7)) << 4) + lhi * 8) = slab_u2{b0, b1};
                 }
-                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                const u32x4_t o = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
-#if defined(SDV_LIN_NOSTORE)     // TIMING-ONLY: one store per block instead of 20 (the values stay live through it)
-                if (t == 9 && qp == 1) __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, vo + (32 * t + 16 * qp) * 2, 0, 0);
-                else asm volatile("" ::"v"(o));
-#else
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, vo + (32 * t + 16 * qp) * 2, 0, 0);
-#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (a wave's DS operations execute in order; this keeps the compiler in order too)
+            u32x4_t o[4];
+            if (!tr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 8 * j + (lane >> 3);
+                    o[j] = *(const slab_u4*)(slab + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                }
+            } else {
+                typedef short __attribute__((ext_vector_type(4))) s16x4_t;
+                typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
+                // lane (g = lane >> 4, i = lane & 15) addresses row 8 g + 4 h + (i >> 2), channels 16 j + 4 (i & 3) .. + 3, and receives
+                // the four rows of channel 16 j + i
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s16x4_t part[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = 8 * (lane >> 4) + 4 * h + ((lane & 15) >> 2);
+                        const int c16 = 2 * j + ((lane & 3) >> 1);
+                        part[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(slab + row * 128 + ((c16 ^ (row & 7)) << 4) + (lane & 1) * 8));
+                    }
+                    typedef short __attribute__((ext_vector_type(8))) s16x8_t;
+                    o[j] = __builtin_bit_cast(u32x4_t, s16x8_t{part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]});
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(o[j], rs_o, vo[j], tr ? sl * 64 * p.ldvt * 2 : sl * 128, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slice's reads are done before the next one is parked
+        }
     };
 
     // ---- one step = one half slab: J = its position in the block's 10 (slot J % 5, k slab J / 2, rows half J % 2); J = 10: the fold
@@ -759,11 +812,14 @@ extern "C" int sdv_ffn_geglu_bf16(const sdv_bf16* X, const float* ln_stats, int6
 
 extern "C" int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
                                   const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps,
-                                  void* stream) {
+                                  sdv_bf16* Vt, int32_t ldvt, int32_t hw, void* stream) {
     SDV_REQUIRE(X && W && Wx && out, "sdv_linear320_bf16: null pointer");
     SDV_REQUIRE(N == FC || N == 3 * FC, "sdv_linear320_bf16: N must be 320 or 960, got %d", N);
     SDV_REQUIRE(M > 0 && M < (1LL << 31) - 128, "sdv_linear320_bf16: bad M");
-    SDV_REQUIRE(ldx >= FC && ldo >= N && ldx % 8 == 0 && ldo % 8 == 0 && (!R || (ldr >= FC && ldr % 8 == 0)), "sdv_linear320_bf16: leading dimensions must be multiples of 8 and cover the rows");
+    SDV_REQUIRE(ldx >= FC && ldo >= (Vt ? 2 * FC : N) && ldx % 8 == 0 && ldo % 8 == 0 && (!R || (ldr >= FC && ldr % 8 == 0)), "sdv_linear320_bf16: leading dimensions must be multiples of 8 and cover the rows");
+    SDV_REQUIRE(!Vt || (N == 3 * FC && hw > 0 && hw % 128 == 0 && M % hw == 0 && ldvt >= hw && ldvt % 8 == 0 && (((uintptr_t)Vt) & 15) == 0),
+                "sdv_linear320_bf16: a transposed V^T output goes with N = 960, whole samples of hw %% 128 == 0 tokens and ldvt >= hw");
+    SDV_REQUIRE(M * (long long)ldx * 2 < 0x7fffffffLL, "sdv_linear320_bf16: the x rows must span less than 2 GiB");
     SDV_REQUIRE(!R || (N == FC && !ln_stats && !alpha), "sdv_linear320_bf16: a residual goes with N = 320 and no fold / alpha (it is the accumulators' initial value)");
     SDV_REQUIRE(!stats_out || N == FC, "sdv_linear320_bf16: row statistics exist for N = 320");
     SDV_REQUIRE(((((uintptr_t)X) | ((uintptr_t)out) | ((uintptr_t)W) | ((uintptr_t)Wx) | ((uintptr_t)R)) & 15) == 0 &&
@@ -784,7 +840,7 @@ extern "C" int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, con
             attr_set |= 1ull << dev;
         }
         const int npanels = (int)((M + 127) >> 7);
-        lin_args a{X, W, Wx, ln_stats, alpha, R, out, stats_out, M, ldx, ldr, ldo, eps};
+        lin_args a{X, W, Wx, ln_stats, alpha, R, out, stats_out, Vt, M, ldx, ldr, ldo, ldvt, hw, eps};
         hipLaunchKernelGGL(kern, dim3((unsigned)(npanels < cus[dev] ? npanels : cus[dev])), dim3(256), LIN_LDS, (hipStream_t)stream, a);
     };
     if (N == FC) {

@@ -42,6 +42,16 @@ def _tap(name: str, kind: str, **kw):
         TAP(name, dict(kind=kind, **kw))
 
 
+# tools/contention_probe.py: tensors BETWEEN the kernels of a block (LayerNorm row statistics, the GEGLU hidden rows) that no block
+# boundary shows - callback (name, tensor), None = no overhead
+TAP_AUX = None
+
+
+def _aux(name: str, what: str, t):
+    if TAP_AUX is not None and t is not None:
+        TAP_AUX(f"{name}:{what}", t)
+
+
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -267,13 +277,21 @@ class _Transformer:
         h_in = h
         # --- self attention: LN1 lives inside the fused Q / K / V projection ---
         qs = hip.q_prescale(dh)       # softmax scale * log2(e), applied by the Q projections before their single rounding
-        if self.lin320:
-            qkv = hip.linear320(h, self.wqkv1, self.wx_qkv, ln_stats=st1, alpha=self.al_qkv)          # [Mb, 3C] = [Q * qs | K | V]
-        else:
-            qkv = hip.linear(h, self.wqkv1, self.tqkv1, alpha=qs, alpha_cols=C, ln=(st1, self.sqkv1))
         o = torch.empty((Mb, C), dtype=BF16, device=x.device)
-        hip.attention(qkv, qkv, qkv, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C,
-                      scale=scale, k_off=C, v_off=2 * C, q_prescaled=True, v_rowmajor=True)
+        if self.lin320 and HW % 128 == 0 and hip.QKV_VT:
+            # [Q * qs | K] row-major + V TRANSPOSED per sample, straight out of the projection's epilogue: the attention kernel's
+            # one-read-per-fragment form (4 % faster than the transposing LDS reads of the row-major V at dh 40)
+            vt = torch.empty((nb, C, HW), dtype=BF16, device=x.device)
+            qk = hip.linear320(h, self.wqkv1, self.wx_qkv, ln_stats=st1, alpha=self.al_qkv, vt=vt, hw=HW)
+            hip.attention(qk, qk, vt, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=HW, ldo=C, scale=scale, k_off=C,
+                          q_prescaled=True)
+        else:
+            if self.lin320:
+                qkv = hip.linear320(h, self.wqkv1, self.wx_qkv, ln_stats=st1, alpha=self.al_qkv)      # [Mb, 3C] = [Q * qs | K | V]
+            else:
+                qkv = hip.linear(h, self.wqkv1, self.tqkv1, alpha=qs, alpha_cols=C, ln=(st1, self.sqkv1))
+            hip.attention(qkv, qkv, qkv, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C,
+                          scale=scale, k_off=C, v_off=2 * C, q_prescaled=True, v_rowmajor=True)
         if self.lin320:
             h, st2 = hip.linear320(o, self.wo1, self.wx_o1, residual=h, want_stats=True)
         else:
@@ -311,12 +329,14 @@ class _Transformer:
                                sX=Mb * C, sW=0, sC=Mb * C, sR=0, want_stats=True)
             h = h2
         _tap(self.name, "tf_attn2", x=h_in, out=h, nimg=nb, H=H, W=W, shared_prefix=shared_prefix)
+        _aux(self.name, "st3", st3)
         h_in = h
         # --- GEGLU feed-forward (LN3 inside ff.net.0) ---
         if self.ffn_fused:
             h = hip.ffn_geglu(h, st3, self.wff1, self.w1x, self.w2p, self.bff2)
         else:
             g = hip.linear(h, self.wff1, self.bff1, epi=1, ln=(st3, self.sff1))   # [M, 4C]
+            _aux(self.name, "ff_hidden", g)
             h = hip.linear(g, self.wff2, self.bff2, residual=h)
         _tap(self.name, "tf_ff", x=h_in, out=h, nimg=nimg, H=H, W=W)
         if not shared_prefix:

@@ -56,7 +56,7 @@ _SIGNATURES = {
     "sdv_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "sdv_ffn_geglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_void_p]),
     "sdv_linear320_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]),
+                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -528,7 +528,7 @@ def ffn_geglu(x: torch.Tensor, ln_stats: torch.Tensor, w1: torch.Tensor, w1x: to
     return out
 
 
-def _linear320_impl(x, w, wx, ln_stats, alpha, residual, out, stats_out, eps):
+def _linear320_impl(x, w, wx, ln_stats, alpha, residual, out, stats_out, eps, vt, hw):
     lib = load()
     M, N = x.shape[0], w.shape[0]
     if x.shape[1] != 320 or w.shape[1] != 320 or tuple(wx.shape) != (N, 16) or not (w.is_contiguous() and wx.is_contiguous()):
@@ -537,27 +537,31 @@ def _linear320_impl(x, w, wx, ln_stats, alpha, residual, out, stats_out, eps):
         raise SdvHipError("linear320: alpha holds one factor per block of 320 output columns")
     args = (_ptr(x, BF16, "X"), M, x.stride(0), _ptr(w, BF16, "W"), _ptr(wx, BF16, "Wx"), N, _ptr(ln_stats, F32, "ln_stats"), _ptr(alpha, F32, "alpha"),
             _ptr(residual, BF16, "R"), residual.stride(0) if residual is not None else 0, _ptr(out, BF16, "out"), out.stride(0),
-            _ptr(stats_out, F32, "stats_out"), float(eps))
+            _ptr(stats_out, F32, "stats_out"), float(eps), _ptr(vt, BF16, "Vt"), vt.stride(1) if vt is not None else 0, int(hw))
+    if vt is not None and (vt.dim() != 3 or vt.shape[0] * hw != M or vt.shape[1] != 320 or vt.stride(2) != 1 or vt.stride(0) != 320 * vt.stride(1)):
+        raise SdvHipError(f"linear320: vt must be [M / hw, 320, ldv] with unit token stride, got {tuple(vt.shape)} / strides {vt.stride()}")
     nbytes = 2.0 * M * (320 + N + (320 if residual is not None else 0))
     _launch("linear320", dict(M=M, N=N, K=320, flops=2.0 * M * N * 320, bytes=nbytes),
             lambda: _check(lib.sdv_linear320_bf16(*args, _stream()), "sdv_linear320_bf16"))
 
 
 _k_linear320 = _defop("k_linear320(Tensor x, Tensor w, Tensor wx, Tensor? ln_stats, Tensor? alpha, Tensor? residual, Tensor(a!) out, Tensor(b!)? stats_out, "
-                      "float eps) -> ()", _linear320_impl)
+                      "float eps, Tensor(c!)? vt, int hw) -> ()", _linear320_impl)
 LINEAR320 = os.environ.get("SDV_LINEAR320", "1") != "0"     # A/B knob: 0 = the C = 320 projections on the igemm tiles (round 5)
+QKV_VT = os.environ.get("SDV_QKV_VT", "1") != "0"           # A/B knob: 0 = V stays row-major in the fused [Q | K | V] buffer
 
 
 def linear320(x: torch.Tensor, w: torch.Tensor, wx: torch.Tensor, *, ln_stats=None, alpha=None, residual=None, out=None, want_stats: bool = False,
-              eps: float = 1e-5, stats_out=None):
+              eps: float = 1e-5, stats_out=None, vt=None, hw: int = 0):
     """A C = 320 projection on the panel kernel (``torch.ops.sdv.k_linear320`` -> sdv_linear320_bf16): N = 320 or 960 output
     columns, bias / LayerNorm fold in ``wx`` (``weights.ffn_fold_columns(s, t)``), optional per-320-column ``alpha``, residual and the
-    LayerNorm statistics of the stored rows (returned as ``(y, stats [M, 2])`` with ``want_stats``)."""
+    LayerNorm statistics of the stored rows (returned as ``(y, stats [M, 2])`` with ``want_stats``).  ``vt`` [M / hw, 320, ldv]
+    (N = 960): the V third is stored transposed per sample of ``hw`` tokens and ``out`` [M, 640] holds only [Q | K]."""
     M = x.shape[0]
     if out is None:
-        out = torch.empty((M, w.shape[0]), dtype=BF16, device=x.device)
+        out = torch.empty((M, w.shape[0] if vt is None else 640), dtype=BF16, device=x.device)
     st = (stats_out if stats_out is not None else torch.empty((M, 2), dtype=F32, device=x.device)) if want_stats else None
-    _k_linear320(x, w, wx, ln_stats, alpha, residual, out, st, float(eps))
+    _k_linear320(x, w, wx, ln_stats, alpha, residual, out, st, float(eps), vt, int(hw))
     return (out, st) if want_stats else out
 
 

@@ -205,3 +205,23 @@ def test_linear320_agrees_with_the_igemm_form(hip, dev):
     assert float((a != b).float().mean()) < 0.01 and float(((a.float() - b.float()).abs() / ulp).max()) <= 2.0
     assert torch.equal(ya, yb) or float((ya != yb).float().mean()) < 0.01
     assert float((sa[:, 0] - sb[:, 0]).abs().max()) < 1e-4 * float(ya.float().abs().max()) and float(((sa[:, 1] - sb[:, 1]) / sb[:, 1]).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("hw,nimg,pad", [(128, 3, 0), (1024, 5, 64), (4096, 4, 0), (4096, 37, 0)])
+def test_linear320_transposed_v_is_the_same_rows_moved(hip, dev, hw, nimg, pad):
+    """The fused Q K V projection with ``Vt``: attention's P V product wants V with the token axis contiguous (the attention forward
+    inside unet(...), stable_diffusion_pipeline.py:418), so the panel kernel stores the V third as [sample][channel][token] straight
+    from its epilogue.  A layout move only: [Q | K] and V^T hold bit for bit the values of the plain [M, 960] launch (sample counts
+    that leave the persistent grid a ragged tail, a padded ldvt), and what lies beyond hw in a padded V^T row is not touched."""
+    M = hw * nimg
+    f = _lin_forms(hip, dev)["qkv"]
+    x, st = _rows(M, dev, 91 + hw)
+    full = hip.linear320(x, f["w"], f["wx"], ln_stats=st, alpha=f["alpha"])
+    store = torch.full((nimg, C, hw + pad), 7.0, dtype=BF16, device=dev)
+    vt = store[:, :, :hw]
+    qk = hip.linear320(x, f["w"], f["wx"], ln_stats=st, alpha=f["alpha"], vt=vt, hw=hw)
+    torch.cuda.synchronize()
+    assert qk.shape == (M, 2 * C) and torch.equal(qk, full[:, :2 * C])
+    assert torch.equal(vt, full[:, 2 * C:].reshape(nimg, hw, C).transpose(1, 2))
+    assert pad == 0 or bool((store[:, :, hw:] == 7.0).all())
+    report(f"linear320 Q K V with V^T, {nimg} samples of {hw} tokens (ldvt {hw + pad}): [Q | K] and V^T bit-identical to the row-major launch")

@@ -75,9 +75,12 @@ def test_ffn_argument_validation_without_gpu(hip):
 def test_linear320_argument_validation_without_gpu(hip):
     """sdv_linear320_bf16: N is 320 or 960, a residual excludes fold / alpha / N = 960, statistics exist for N = 320 only"""
     lib = hip.load()
-    ok = dict(X=16, M=4096, ldx=320, W=16, Wx=16, N=320, ln_stats=None, alpha=None, R=None, ldr=0, out=16, ldo=320, stats_out=None, eps=1e-5, stream=None)
+    ok = dict(X=16, M=4096, ldx=320, W=16, Wx=16, N=320, ln_stats=None, alpha=None, R=None, ldr=0, out=16, ldo=320, stats_out=None, eps=1e-5,
+              Vt=None, ldvt=0, hw=0, stream=None)
     for change, word in ((dict(N=640), b"320 or 960"), (dict(R=16, ldr=320, ln_stats=16), b"residual"), (dict(N=960, ldo=960, stats_out=16), b"statistics"),
-                         (dict(N=960, ldo=320), b"leading"), (dict(W=None), b"null"), (dict(X=18), b"unaligned")):
+                         (dict(N=960, ldo=320), b"leading"), (dict(W=None), b"null"), (dict(X=18), b"unaligned"),
+                         (dict(Vt=16, ldo=640, ldvt=4096, hw=4096), b"V^T"), (dict(N=960, ldo=640, Vt=16, ldvt=4096, hw=4000), b"V^T"),
+                         (dict(N=960, ldo=640, Vt=16, ldvt=4096, hw=4096, M=4096 + 128), b"V^T")):
         a = dict(ok)
         a.update(change)
         assert lib.sdv_linear320_bf16(*a.values()) == -1 and word in lib.sdv_last_error(), (change, lib.sdv_last_error())
@@ -690,9 +693,9 @@ def test_bench_reads_the_committed_pmc_profile(tmp_path):
     spec.loader.exec_module(bench)
     fp = bench.csrc_fingerprint()
     assert len(fp) == 16 and fp == bench.csrc_fingerprint()
-    for name in ("round5_pmc_unet_b128.csv", "round5_bench_b128_kernel_stats.csv"):
+    for name in ("round6_pmc_unet_b128.csv", "round6_bench_b128_kernel_stats.csv"):
         assert bench.profile_fingerprint(ROOT / "profiles" / name) == fp, \
-            f"profiles/{name} was not collected from the kernel sources of this tree: re-run tools/run_profiles_r5.sh and commit its summaries"
+            f"profiles/{name} was not collected from the kernel sources of this tree: re-run tools/run_profiles_r6.sh and commit its summaries"
     pmc = bench.pmc_profile(128)
     tr = bench.dominant_kernel_traffic(pmc)
     assert tr and tr["kernel"].startswith("igemm_kernel<4, 2, 2, 5, 64, true")
@@ -710,10 +713,10 @@ def test_bench_reads_the_committed_pmc_profile(tmp_path):
         (tmp_path / "profiles").mkdir()
         (tmp_path / "stable_diffusion_videos_amd").symlink_to(real_root / "stable_diffusion_videos_amd")
         (tmp_path / "include").symlink_to(real_root / "include")
-        body = (real_root / "profiles" / "round5_pmc_unet_b128.csv").read_text().split("\n", 1)[1]
-        (tmp_path / "profiles" / "round5_pmc_unet_b128.csv").write_text("# csrc=0123456789abcdef somebody else's kernels\n" + body)
+        body = (real_root / "profiles" / "round6_pmc_unet_b128.csv").read_text().split("\n", 1)[1]
+        (tmp_path / "profiles" / "round6_pmc_unet_b128.csv").write_text("# csrc=0123456789abcdef somebody else's kernels\n" + body)
         assert bench.pmc_profile(128) == {} and "not replayed" in bench.pmc_profile.stale
-        (tmp_path / "profiles" / "round5_pmc_unet_b128.csv").write_text(body)             # no fingerprint at all (a round-4 file)
+        (tmp_path / "profiles" / "round6_pmc_unet_b128.csv").write_text(body)             # no fingerprint at all (a round-4 file)
         assert bench.pmc_profile(128) == {} and "unrecorded" in bench.pmc_profile.stale
     finally:
         bench.ROOT = real_root

@@ -6,7 +6,7 @@ bit-reproducible; SDV_LN_FOLD=0 makes the difference go away.)
 Foreground: the tiny UNet's eager forward with engine.TAP recording every block / sub-block output - once alone (baseline), then
 RUNS times while a child process runs the same forward in a loop; per tap name the number of runs whose output differs from
 the baseline, in forward order (the first name with a non-zero count is where it starts).
-usage: python tools/contention_probe.py [runs] [arch]        (internal: ... noise <seconds> <arch>)"""
+usage: python tools/contention_probe.py [runs] [arch] [noise arch]        (internal: ... noise <seconds> <arch>)"""
 import subprocess
 import sys
 import time
@@ -49,10 +49,11 @@ def noise(seconds, arch):
 def tapped_forward(pipe, x2, B, h, step):
     rec = []
     engine.TAP = lambda name, d: rec.append((f"{name}:{d['kind']}", d["out"].detach().clone()))
+    engine.TAP_AUX = lambda name, t: rec.append((name, t.detach().clone()))
     try:
         eps = pipe.unet.forward(x2, 2 * B, h, h, step, cfg_shared=True)
     finally:
-        engine.TAP = None
+        engine.TAP = engine.TAP_AUX = None
     torch.cuda.synchronize()
     rec.append(("eps", eps.clone()))
     return rec
@@ -66,8 +67,10 @@ def main():
     again = tapped_forward(pipe, x2, B, h, step)
     alone = sum(not torch.equal(a[1], b[1]) for a, b in zip(base, again))
     print(f"{arch}: {len(base)} taps; alone, second forward vs first: {alone} taps differ", flush=True)
-    child = subprocess.Popen([sys.executable, __file__, "noise", "90", arch])
-    time.sleep(12 if arch == "tiny" else 40)
+    noise_arch = sys.argv[3] if len(sys.argv) > 3 else arch
+    child = subprocess.Popen([sys.executable, __file__, "noise", "600", noise_arch], stdout=subprocess.PIPE, text=True)
+    while "ready" not in child.stdout.readline():
+        pass
     counts = [0] * len(base)
     firsts = {}
     try:

@@ -49,10 +49,10 @@ def run_old(x, st, res, F, name):
     return hip.linear(x, F["w"], F["t"], alpha=F["qs"], ln=(st, F["s"])), None
 
 
-def run_new(x, st, res, F, name):
+def run_new(x, st, res, F, name, vt=None, hw=0):
     if name == "bias+stats":
         return hip.linear320(x, F["w"], F["wx"], residual=res, want_stats=True)
-    return hip.linear320(x, F["w"], F["wx"], ln_stats=st, alpha=F["alpha"]), None
+    return hip.linear320(x, F["w"], F["wx"], ln_stats=st, alpha=F["alpha"], vt=vt, hw=hw), None
 
 
 def reference(x, st, res, F, name):
@@ -91,6 +91,19 @@ def main():
                 true = stats_of(a)
                 msg += f"   stats: max|mean err| {float((sa[:, 0] - true[:, 0]).abs().max()):.2e} max rel rstd err {float(((sa[:, 1] - true[:, 1]) / true[:, 1]).abs().max()):.2e}"
             print(msg)
+    # transposed V output: [Q | K] + V^T must be the row-major result, re-arranged
+    for M, hw in ((1024, 256), (4096 * 3, 4096), (128 * 20, 128)):
+        g = torch.Generator().manual_seed(M)
+        x = (torch.randn(M, C, generator=g) * 1.5 + torch.randn(M, 1, generator=g) * 3.0).to(dev, BF16)
+        st = stats_of(x)
+        F = FS["qkv fold"]
+        full, _ = run_new(x, st, None, F, "qkv fold")
+        vt = torch.zeros((M // hw, C, hw + 64), dtype=BF16, device=dev)[:, :, :hw]
+        qk, _ = run_new(x, st, None, F, "qkv fold", vt=vt, hw=hw)
+        torch.cuda.synchronize()
+        ok_qk = bool(torch.equal(qk, full[:, :2 * C]))
+        ok_vt = bool(torch.equal(vt, full[:, 2 * C:].reshape(M // hw, hw, C).transpose(1, 2)))
+        print(f"M={M} hw={hw}: [Q | K] identical {ok_qk}, V^T identical {ok_vt}")
     M = nimg * 4096
     x = (torch.randn(M, C, device=dev) * 1.5).to(BF16)
     r = (torch.randn(M, C, device=dev) * 2.0).to(BF16)
@@ -116,6 +129,9 @@ def main():
             to = timed(lambda: run_old(x, st, r if use_r else None, F, name))
             gb = 2.0 * M * (C + F["N"] + (C if use_r else 0)) / 1e9
             print(f"M={M} {name:10s} res={int(use_r)}: panel {tn:.3f} ms ({gb / tn:.2f} TB/s)   igemm {to:.3f} ms ({gb / to:.2f} TB/s)   x{to / tn:.2f}")
+        vtb = torch.empty((nimg, C, 4096), dtype=BF16, device=dev)
+        tv = timed(lambda: run_new(x, st, None, FS["qkv fold"], "qkv fold", vt=vtb, hw=4096))
+        print(f"M={M} qkv fold with transposed V: panel {tv:.3f} ms")
 
 
 if __name__ == "__main__":
