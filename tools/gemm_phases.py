@@ -26,6 +26,8 @@ def main():
                                                       ("gemm 320->320 @64 +res", 64, 320, 320, True, False, False),
                                                       ("gemm 320->2560 geglu @64", 64, 320, 2560, False, True, False),
                                                       ("gemm 1280->320 @64 +res", 64, 1280, 320, True, False, False),
+                                                      ("gemm 640->640 @32", 32, 640, 640, False, False, False),
+                                                      ("conv 320->320 @64", 64, 320, 320, False, False, True),
                                                       ("conv 320->320 @64 +res", 64, 320, 320, True, False, True)):
         M = nimg * H * H
         kk = 9 * cin if conv else cin
