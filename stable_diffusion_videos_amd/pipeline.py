@@ -757,6 +757,34 @@ class StableDiffusionWalkPipeline:
         if self._writer is None:
             writer.close()
 
+    # ``resume=True``: which frames of a clip are (re)generated.  "holes" (default) = every frame whose file is missing or empty;
+    # "reference" = the reference's rule, bit for bit (:741-753): continue behind the LAST frame on disk, whatever lies before it,
+    # and skip a clip whose last frame is num_step - 2 or later (its one-missing-frame quirk included) - only right for ONE sequential
+    # writer, so it is meant for single-rank walks that must leave exactly the reference's files.  SDV_RESUME=reference selects it.
+    resume_policy = os.environ.get("SDV_RESUME", "holes")
+
+    @staticmethod
+    def resume_todo(save_path, mp4_path, num_step: int, image_file_ext: str = ".png", policy: str = "holes"):
+        """Frames of one clip a resumed walk has to generate (ascending list), or None when the clip is skipped."""
+        if policy not in ("holes", "reference"):
+            raise ValueError(f"resume policy must be 'holes' or 'reference', got {policy!r}")
+        save_path = Path(save_path)
+        if Path(mp4_path).exists():
+            return None
+        if policy == "reference":
+            existing = sorted(save_path.glob(f"*{image_file_ext}"))
+            if not existing:
+                return list(range(num_step))
+            skip = int(existing[-1].stem[-6:]) + 1
+            return None if skip + 1 >= num_step else list(range(skip, num_step))
+        have = set()
+        for f in save_path.glob(f"frame*{image_file_ext}"):
+            digits = f.stem[len("frame"):]
+            if len(digits) == 6 and digits.isdigit() and f.stat().st_size > 0:
+                have.add(int(digits))
+        todo = [k for k in range(num_step) if k not in have]
+        return todo or None
+
     def walk(self, prompts: Optional[List[str]] = None, seeds: Optional[List[int]] = None,
              num_interpolation_steps: Optional[Union[int, List[int]]] = 5, output_dir: Optional[str] = "./dreams",
              name: Optional[str] = None, image_file_ext: Optional[str] = ".png", fps: Optional[int] = 30,
@@ -816,7 +844,8 @@ class StableDiffusionWalkPipeline:
         # leaves holes (rank 0 died at frame 20 of its block, rank 1 at frame 70 of its own).  Resume therefore regenerates
         # exactly the frames whose file is missing or empty (frames are renamed into place only when complete) - for the
         # reference's own on-disk states this is the same set, except that its :750 quirk (a clip with exactly one missing
-        # frame is skipped and stays incomplete) is not reproduced.
+        # frame is skipped and stays incomplete) is not reproduced.  `resume_policy = "reference"` (SDV_RESUME=reference) switches
+        # to the reference's rule bit for bit: `resume_todo`.
         clips, all_clips = [], {}
         for i, (prompt_a, prompt_b, seed_a, seed_b, num_step) in enumerate(
                 zip(prompts, prompts[1:], seeds, seeds[1:], num_interpolation_steps)):
@@ -826,20 +855,12 @@ class StableDiffusionWalkPipeline:
             all_clips[i] = dict(i=i, prompt_a=prompt_a, prompt_b=prompt_b, seed_a=seed_a, seed_b=seed_b, num_step=num_step,
                                 todo=todo, save_path=save_path, mp4=step_output_filepath)
             if resume:
-                if step_output_filepath.exists():
+                todo = self.resume_todo(save_path, step_output_filepath, num_step, image_file_ext, self.resume_policy)
+                if todo is None:
                     print(f"Skipping {save_path} because frames already exist")
                     continue
-                have = set()
-                for f in save_path.glob(f"frame*{image_file_ext}"):
-                    digits = f.stem[len("frame"):]
-                    if len(digits) == 6 and digits.isdigit() and f.stat().st_size > 0:
-                        have.add(int(digits))
-                todo = [k for k in range(num_step) if k not in have]
-                if not todo:
-                    print(f"Skipping {save_path} because frames already exist")
-                    continue
-                if have:
-                    print(f"Resuming {save_path.name}: {len(todo)} of {num_step} frames missing (first {todo[0]})")
+                if len(todo) < num_step:
+                    print(f"Resuming {save_path.name}: {len(todo)} of {num_step} frames to generate (first {todo[0]})")
             all_clips[i]["todo"] = todo
             clips.append(all_clips[i])
         if world_size > 1:

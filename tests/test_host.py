@@ -721,3 +721,31 @@ def test_bench_reads_the_committed_pmc_profile(tmp_path):
     finally:
         bench.ROOT = real_root
 
+
+
+def test_resume_policies(tmp_path):
+    """walk(resume=True), reference :741-753: "holes" (default) regenerates every missing / empty frame; "reference" continues behind the
+    last frame on disk and reproduces the rule's quirks - a hole before the last frame stays, a clip missing only its last frame is
+    skipped - and both skip a clip whose mp4 exists."""
+    from stable_diffusion_videos_amd.pipeline import StableDiffusionWalkPipeline as P
+    clip = tmp_path / "w_000000"
+    clip.mkdir()
+    mp4 = clip / "w_000000.mp4"
+    for k in (0, 1, 2, 4, 5):
+        (clip / f"frame{k:06d}.png").write_bytes(b"x")
+    (clip / "frame000006.png").write_bytes(b"")                       # a zero-byte file: killed while writing
+    assert P.resume_todo(clip, mp4, 10) == [3, 6, 7, 8, 9]
+    assert P.resume_todo(clip, mp4, 10, policy="reference") == [7, 8, 9]      # behind the LAST file, hole 3 and the empty 6 stay
+    assert P.resume_todo(clip, mp4, 8, policy="reference") is None            # last = num_step - 2: the :750 quirk skips the clip
+    assert P.resume_todo(clip, mp4, 8) == [3, 6, 7]
+    for k in (3, 6, 7):
+        (clip / f"frame{k:06d}.png").write_bytes(b"x")
+    assert P.resume_todo(clip, mp4, 8) is None and P.resume_todo(clip, mp4, 8, policy="reference") is None
+    empty = tmp_path / "w_000001"
+    empty.mkdir()
+    assert P.resume_todo(empty, empty / "w_000001.mp4", 3) == [0, 1, 2] == P.resume_todo(empty, empty / "w_000001.mp4", 3, policy="reference")
+    mp4.write_bytes(b"v")
+    assert P.resume_todo(clip, mp4, 99) is None and P.resume_todo(clip, mp4, 99, policy="reference") is None
+    with pytest.raises(ValueError):
+        P.resume_todo(clip, mp4, 8, policy="other")
+    assert P.resume_policy in ("holes", "reference")
