@@ -199,6 +199,13 @@ int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16
                        const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps,
                        sdv_bf16* Vt, int32_t ldvt, int32_t hw, void* stream);
 
+/* The same kernel for C = 640 rows (the 32 x 32 level): N = 640 (proj_in with stats_out, attn2.to_q) or 1920 (the fused Q K V projection,
+ * row-major), formula and operands as sdv_linear320_bf16 with W [N][640] and alpha [N / 320].  No residual form and no transposed V: the
+ * 40 input fragments of a wave's 32 rows already take 160 of its registers (attn.to_out / proj_out stay on sdv_gemm_bf16).
+ * stats_out is available for N = 640. */
+int sdv_linear640_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
+                       const float* alpha, sdv_bf16* out, int32_t ldo, float* stats_out, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Flash-style attention, softmax(Q K^T * scale) V, never materialising the score matrix.
  * Replaces CrossAttention.forward inside the UNet (self: Lk = Lq; cross: Lk = 77).

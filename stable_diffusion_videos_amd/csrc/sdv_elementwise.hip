@@ -17,7 +17,7 @@ void sdv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sdv_last_error(void) { return g_err; }
-extern "C" int sdv_abi_version(void) { return 11; }
+extern "C" int sdv_abi_version(void) { return 12; }
 
 namespace {
 

@@ -406,7 +406,9 @@ constexpr int LIN_STAGE_OFF = LIN_FOLD_OFF + LFOLD_BYTES;  // three 16 KiB slots
 constexpr int LIN_LDS = LIN_STAGE_OFF + 3 * 16384;
 static_assert(LIN_LDS <= 160 * 1024, "ring + fold columns + x staging must fit the 160 KiB LDS");
 
-template <int NB, bool RES>
+// KSL = 64-wide k slabs of the input rows: 5 (C = 320) or 10 (C = 640; the x rows are then 40 fragments = 160 registers, which is
+// why there is no residual form: its 20 more fragments do not fit one wave per SIMD)
+template <int NB, bool RES, int KSL = 5>
 __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -414,6 +416,8 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
     const int npanels = (int)((p.M + 127) >> 7);
+    constexpr int KC = 64 * KSL, NS = 2 * KSL;        // input channels; half-slab steps per block (step NS = the fold k-step)
+    static_assert(KSL == 5 || (KSL == 10 && !RES), "k slabs per row: 5, or 10 without the residual form");
 
     auto swz = [](int r) { return (r >> 1) & 7; };
     const int rg = lane >> 3, pc = lane & 7;
@@ -421,19 +425,19 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int r = (wave + 4 * i) * 8 + rg;
-        voW[i] = (unsigned)(r * (FC * 2) + ((pc ^ swz(r)) << 4));
+        voW[i] = (unsigned)(r * (KC * 2) + ((pc ^ swz(r)) << 4));
     }
     unsigned voF[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) voF[i] = (unsigned)(((wave + 4 * i) * 32 + (lane >> 1)) * 32 + (lane & 1) * 16);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, NB * FC * FC * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, NB * FC * KC * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wx, 0, NB * FC * 32, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // piece i of half slab (block blk, k slab ks, half hf) -> ring slot `slot`
     auto pieceW = [&](auto SLOT, int blk, auto KS, auto HF, auto I) __attribute__((always_inline)) {
         constexpr int slot = decltype(SLOT)::value, ks = decltype(KS)::value, hf = decltype(HF)::value, i = decltype(I)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + slot * SLOT_B + (wave + 4 * i) * 1024), 16, (int)voW[i],
-                                                 (blk * FC + hf * 160) * (FC * 2) + ks * 128, 0, 0);
+                                                 (blk * FC + hf * 160) * (KC * 2) + ks * 128, 0, 0);
     };
     auto pieceF = [&](int blk, auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
         else return *(const bf16x8_t*)(smem + slot * SLOT_B + (i % 5) * 4096 + fo[(i / 5) & 3]);
     };
 
-    bf16x8_t xf[21];
+    bf16x8_t xf[4 * KSL + 1];
     bf16x8_t rf[RES ? 20 : 1];
     float rs = 1.f, nrs = 1.f;
     float2 nst = make_float2(0.f, 1.f);
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
     // ks 6: the statistics of the rows are REQUESTED (early); ks 5: they are split into the fold k-step's token side (late)
     auto load_x = [&](int panel, auto KS) __attribute__((always_inline)) {
         constexpr int ks = decltype(KS)::value;
-        static_assert(ks >= 5, "k slabs 0 .. 4 go through stage_x / read_x");
+        static_assert(ks >= 5, "the k slabs go through stage_x / read_x; 5 / 6 name the two halves of the statistics load");
         const long long tok = tok_of(panel);
         if constexpr (ks == 6) {      // (the statistics are REQUESTED early - ks 6 - and split into the fold fragment late - ks 5)
             nst = make_float2(0.f, 1.f);
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
             split3(1.0f / rstd, rh, rm, rl);
             const u32x4_t lo = u32x4_t{mh | (mm << 16), mh | (ml << 16), mh | (mm << 16), rh | (rm << 16)};
             const u32x4_t hi = u32x4_t{rh | (rl << 16), rh | (rm << 16), 0u, 0u};
-            xf[20] = __builtin_bit_cast(bf16x8_t, lhi ? hi : lo);
+            xf[4 * KSL] = __builtin_bit_cast(bf16x8_t, lhi ? hi : lo);
         }
     };
     auto load_r = [&](int panel) __attribute__((always_inline)) {
@@ -558,8 +562,8 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
         // EVERY wave issues all 20 stores of a block whatever M is - the counted vmcnt waits of the steps behind rely on that
         const long long row0 = (long long)panel * 128 + wave * 32;
         const long long left = p.M - row0;
-        const bool tr = p.Vt != nullptr && blk == 2;
-        char* const slab = smem + LIN_STAGE_OFF + 2 * 16384 + wave * 4096;
+        const bool tr = (NB == 3 && KSL == 5) && p.Vt != nullptr && blk == 2;       // (the other forms compile no transposed path)
+        char* const slab = smem + LIN_STAGE_OFF + ((KSL - 3) % 3) * 16384 + wave * 4096;      // (the staging slot no pending k slab lives in)
         const unsigned ones = 0x3f803f80u;
         __amdgpu_buffer_rsrc_t rs_o;
         int vo[4];
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
             rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (left > 0 ? row0 : 0) * p.ldo), 0,
                                                      left > 0 ? (int)((left < 32 ? left : 32) * p.ldo * 2) : 0, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vo[j] = ((8 * j + (lane >> 3)) * p.ldo + blk * FC + 8 * (lane & 7)) * 2;
+            for (int j = 0; j < 4; ++j) vo[j] = ((8 * j + (lane >> 3)) * p.ldo + 8 * (lane & 7)) * 2;      // (the block's column offset rides in the scalar offset)
         } else {
             // V^T[sample][channel][token]: this wave's 32 tokens are tokens t0 .. t0 + 31 of sample b (hw % 128 == 0: host)
             const long long b = row0 / p.hw, t0 = row0 - b * p.hw;
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(o[j], rs_o, vo[j], tr ? sl * 64 * p.ldvt * 2 : sl * 128, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o[j], rs_o, vo[j], tr ? sl * 64 * p.ldvt * 2 : sl * 128 + blk * (FC * 2), 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slice's reads are done before the next one is parked
         }
     };
@@ -651,23 +655,23 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
         constexpr auto tail_ops = [](int s, bool last) constexpr {
             int nn = 0;
             if (s == 0) nn += 3 + ((RES && last) ? 20 : 0);
-            if (last && s < 10 && (s & 1)) nn += 4;
-            if (s == 10) nn += 20;
+            if (last && s < NS && (s & 1)) nn += 4;
+            if (s == NS) nn += 20;
             return nn;
         };
         constexpr auto window = [tail_ops](int j, bool last, bool plast) constexpr {
-            const int need = j < 10 ? j + 1 : 11;                 // stream position (this block's steps 0 .. 9; 11 = the next block's step 0) of the slab needed
-            const int is = (need == 11 ? 10 : need) - 4;          // step that issued it (relative to this block; < 0: the previous block's step is + 11)
+            const int need = j < NS ? j + 1 : NS + 1;             // stream position (this block's steps 0 .. NS - 1; NS + 1 = the next block's step 0) of the slab needed
+            const int is = (need == NS + 1 ? NS : need) - 4;      // step that issued it (relative to this block; < 0: the previous block's step is + NS + 1)
             int nn = 0;
             for (int q = is; q < j; ++q) {
                 const bool lq = q < 0 ? plast : last;
-                const int sq = q < 0 ? q + 11 : q;
-                nn += (q == is ? 0 : (sq < 10 ? 5 : 0)) + tail_ops(sq, lq);
+                const int sq = q < 0 ? q + NS + 1 : q;
+                nn += (q == is ? 0 : (sq < NS ? 5 : 0)) + tail_ops(sq, lq);
             }
             return nn;
         };
-        constexpr int n = J < 10 ? 20 : 10, slot = J < 10 ? J % 5 : 5, ks = J / 2, hf = J % 2;
-        constexpr int nslot = J < 9 ? (J + 1) % 5 : (J == 9 ? 5 : 0);                 // where the NEXT step's fragments are
+        constexpr int n = J < NS ? 20 : 10, slot = J < NS ? J % 5 : 5, ks = J / 2, hf = J % 2;
+        constexpr int nslot = J < NS - 1 ? (J + 1) % 5 : (J == NS - 1 ? 5 : 0);                 // where the NEXT step's fragments are
         __builtin_amdgcn_sched_barrier(0);
         constexpr int VM0 = window(J, lastb, prevlast);
         static_assert(VM0 >= 10 && VM0 <= 63, "vmcnt window");
@@ -681,8 +685,8 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
         asm volatile("" ::: "memory");
         // the next panel's x rows: k slab ks was staged behind step 2 ks + 1 of the panel's last block; the first window that has
         // closed behind it is the one of step 2 ks + 5 - steps 5 / 7 / 9 of that block, steps 1 / 3 of the next panel's first block
-        if constexpr (lastb && (J == 5 || J == 7 || J == 9)) read_x(ic<(J - 5) / 2>{});
-        if constexpr (decltype(FIRSTB)::value != 0 && (J == 1 || J == 3)) read_x(ic<3 + (J - 1) / 2>{});
+        if constexpr (lastb && J >= 5 && J < NS && (J & 1)) read_x(ic<(J - 5) / 2>{});
+        if constexpr (decltype(FIRSTB)::value != 0 && (J == 1 || J == 3)) read_x(ic<KSL - 2 + (J - 1) / 2>{});
         bf16x8_t w[AH + 1], nw[AH];
 #pragma unroll
         for (int a = 0; a < AH; ++a) w[a] = wq[a];
@@ -696,37 +700,42 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
 #if defined(SDV_LIN_NODMA)       // TIMING-ONLY: no weight refills
             if constexpr (false) {
 #else
-            if constexpr (J < 10 && i < 5) {
+            if constexpr (J < NS && i < 5) {
 #endif
-                constexpr int pj = (J + 9) % 10, tj = (pj + 5) % 10;              // step whose slot is free / step whose slab goes there
+                constexpr int pj = (J + NS - 1) % NS, tj = (pj + 5) % NS;              // step whose slot is free / step whose slab goes there
                 // J >= 1: target step tj = J + 4 belongs to this block if J + 4 < 10, else to the next; J == 0: tj = 4 of THIS block
-                pieceW(ic<pj % 5>{}, (J >= 1 && J + 4 >= 10) ? nblk : blk, ic<tj / 2>{}, ic<tj % 2>{}, I);
+                pieceW(ic<pj % 5>{}, (J >= 1 && J + 4 >= NS) ? nblk : blk, ic<tj / 2>{}, ic<tj % 2>{}, I);
             }
             if constexpr (J == 0 && i >= 5 && i < 8) pieceF(blk, ic<i - 5>{});
-            if constexpr (J < 10)
+            if constexpr (J < NS)
                 acc[5 * hf + i % 5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i % (AH + 1)], xf[4 * ks + i / 5],
                                                                               (!RES && ks == 0 && i / 5 == 0) ? kZ16 : acc[5 * hf + i % 5], 0, 0, 0);
             else
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i % (AH + 1)], xf[20], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i % (AH + 1)], xf[4 * KSL], acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
         for (int a = 0; a < AH; ++a) wq[a] = nw[a];
         // the x rows of the next panel, k slab by k slab, once this panel's last block is through with them
-        if constexpr (lastb && J < 10 && hf == 1) stage_x(xnext, ic<ks>{});
+        if constexpr (lastb && J < NS && hf == 1) stage_x(xnext, ic<ks>{});
         if constexpr (lastb && J == 1) load_x(xnext, ic<6>{});
-        if constexpr (lastb && J == 10) load_x(xnext, ic<5>{});
+        if constexpr (lastb && J == NS) load_x(xnext, ic<5>{});
     };
 
     // ---- the walk ------------------------------------------------------------------------------------------------------------
     int cur = blockIdx.x;
     if (cur >= npanels) return;
     load_x(cur, ic<6>{});
-    static_for<0, 3>([&](auto KS) { stage_x(cur, KS); });          // the first panel's x rows, through the three staging slots in two rounds
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_for<0, 3>([&](auto KS) { read_x(KS); });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    static_for<3, 5>([&](auto KS) { stage_x(cur, KS); });          // (slabs 3 / 4 stay in their slots: the first panel's steps 1 / 3 read them again)
+    // the first panel's x rows, through the three staging slots, at most three k slabs per round; the last two stay in their slots:
+    // the first panel's steps 1 / 3 read them (like every later panel's)
+    static_for<0, (KSL - 2 + 2) / 3>([&](auto R) {
+        constexpr int k0 = 3 * decltype(R)::value, k1 = k0 + 3 < KSL - 2 ? k0 + 3 : KSL - 2;
+        static_for<k0, k1>([&](auto KS) { stage_x(cur, KS); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_for<k0, k1>([&](auto KS) { read_x(KS); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    static_for<KSL - 2, KSL>([&](auto KS) { stage_x(cur, KS); });
     load_x(cur, ic<5>{});
     load_r(cur);
     // fill the ring: the first five half slabs of block 0 + its fold columns
@@ -754,16 +763,7 @@ __global__ __launch_bounds__(256, 1) void panel_linear_kernel(const lin_args p) 
                 init_acc(ic<5>{}, ic<10>{});
                 load_r(xn);                       // (the residual registers are free again: the next panel's rows)
             }
-            step(ic<1>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<2>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<3>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<4>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<5>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<6>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<7>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<8>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<9>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
-            step(ic<10>{}, LB{}, PL{}, FB{}, blk, nblk, xn);
+            static_for<1, NS + 1>([&](auto JJ) { step(JJ, LB{}, PL{}, FB{}, blk, nblk, xn); });
             store_block(cur, blk, rs * alf[blk]);
         });
         if (p.stats_out) {
@@ -810,21 +810,22 @@ extern "C" int sdv_ffn_geglu_bf16(const sdv_bf16* X, const float* ln_stats, int6
     return SDV_OK;
 }
 
-extern "C" int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
-                                  const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps,
-                                  sdv_bf16* Vt, int32_t ldvt, int32_t hw, void* stream) {
-    SDV_REQUIRE(X && W && Wx && out, "sdv_linear320_bf16: null pointer");
-    SDV_REQUIRE(N == FC || N == 3 * FC, "sdv_linear320_bf16: N must be 320 or 960, got %d", N);
-    SDV_REQUIRE(M > 0 && M < (1LL << 31) - 128, "sdv_linear320_bf16: bad M");
-    SDV_REQUIRE(ldx >= FC && ldo >= (Vt ? 2 * FC : N) && ldx % 8 == 0 && ldo % 8 == 0 && (!R || (ldr >= FC && ldr % 8 == 0)), "sdv_linear320_bf16: leading dimensions must be multiples of 8 and cover the rows");
-    SDV_REQUIRE(!Vt || (N == 3 * FC && hw > 0 && hw % 128 == 0 && M % hw == 0 && ldvt >= hw && ldvt % 8 == 0 && (((uintptr_t)Vt) & 15) == 0),
-                "sdv_linear320_bf16: a transposed V^T output goes with N = 960, whole samples of hw %% 128 == 0 tokens and ldvt >= hw");
-    SDV_REQUIRE(M * (long long)ldx * 2 < 0x7fffffffLL, "sdv_linear320_bf16: the x rows must span less than 2 GiB");
-    SDV_REQUIRE(!R || (N == FC && !ln_stats && !alpha), "sdv_linear320_bf16: a residual goes with N = 320 and no fold / alpha (it is the accumulators' initial value)");
-    SDV_REQUIRE(!stats_out || N == FC, "sdv_linear320_bf16: row statistics exist for N = 320");
+// K = 320 (N = 320 / 960) and K = 640 (N = 640 / 1920, no residual, no V^T) share the checks and the launch
+static int panel_linear_launch(const char* who, int K, const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N,
+                               const float* ln_stats, const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out,
+                               float eps, sdv_bf16* Vt, int32_t ldvt, int32_t hw, void* stream) {
+    SDV_REQUIRE(X && W && Wx && out, "%s: null pointer", who);
+    SDV_REQUIRE(N == K || N == 3 * K, "%s: N must be %d or %d, got %d", who, K, 3 * K, N);
+    SDV_REQUIRE(M > 0 && M < (1LL << 31) - 128, "%s: bad M", who);
+    SDV_REQUIRE(ldx >= K && ldo >= (Vt ? 2 * K : N) && ldx % 8 == 0 && ldo % 8 == 0 && (!R || (ldr >= K && ldr % 8 == 0)), "%s: leading dimensions must be multiples of 8 and cover the rows", who);
+    SDV_REQUIRE(!Vt || (K == FC && N == 3 * FC && hw > 0 && hw % 128 == 0 && M % hw == 0 && ldvt >= hw && ldvt % 8 == 0 && (((uintptr_t)Vt) & 15) == 0),
+                "%s: a transposed V^T output goes with K = 320, N = 960, whole samples of hw %% 128 == 0 tokens and ldvt >= hw", who);
+    SDV_REQUIRE(M * (long long)ldx * 2 < 0x7fffffffLL, "%s: the x rows must span less than 2 GiB", who);
+    SDV_REQUIRE(!R || (K == FC && N == FC && !ln_stats && !alpha), "%s: a residual goes with K = N = 320 and no fold / alpha (it is the accumulators' initial value)", who);
+    SDV_REQUIRE(!stats_out || N == K, "%s: row statistics exist for N = K", who);
     SDV_REQUIRE(((((uintptr_t)X) | ((uintptr_t)out) | ((uintptr_t)W) | ((uintptr_t)Wx) | ((uintptr_t)R)) & 15) == 0 &&
                     ((((uintptr_t)ln_stats) | ((uintptr_t)stats_out)) & 7) == 0,
-                "sdv_linear320_bf16: unaligned pointers");
+                "%s: unaligned pointers", who);
     static int cus[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -843,12 +844,28 @@ extern "C" int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, con
         lin_args a{X, W, Wx, ln_stats, alpha, R, out, stats_out, Vt, M, ldx, ldr, ldo, ldvt, hw, eps};
         hipLaunchKernelGGL(kern, dim3((unsigned)(npanels < cus[dev] ? npanels : cus[dev])), dim3(256), LIN_LDS, (hipStream_t)stream, a);
     };
-    if (N == FC) {
-        if (R) launch(panel_linear_kernel<1, true>);
-        else launch(panel_linear_kernel<1, false>);
+    if (K == FC) {
+        if (N == FC) {
+            if (R) launch(panel_linear_kernel<1, true>);
+            else launch(panel_linear_kernel<1, false>);
+        } else {
+            launch(panel_linear_kernel<3, false>);
+        }
     } else {
-        launch(panel_linear_kernel<3, false>);
+        if (N == K) launch(panel_linear_kernel<2, false, 10>);
+        else launch(panel_linear_kernel<6, false, 10>);
     }
-    SDV_CHECK_LAUNCH("sdv_linear320_bf16");
+    SDV_CHECK_LAUNCH(who);
     return SDV_OK;
+}
+
+extern "C" int sdv_linear320_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
+                                  const float* alpha, const sdv_bf16* R, int32_t ldr, sdv_bf16* out, int32_t ldo, float* stats_out, float eps,
+                                  sdv_bf16* Vt, int32_t ldvt, int32_t hw, void* stream) {
+    return panel_linear_launch("sdv_linear320_bf16", FC, X, M, ldx, W, Wx, N, ln_stats, alpha, R, ldr, out, ldo, stats_out, eps, Vt, ldvt, hw, stream);
+}
+
+extern "C" int sdv_linear640_bf16(const sdv_bf16* X, int64_t M, int32_t ldx, const sdv_bf16* W, const sdv_bf16* Wx, int32_t N, const float* ln_stats,
+                                  const float* alpha, sdv_bf16* out, int32_t ldo, float* stats_out, float eps, void* stream) {
+    return panel_linear_launch("sdv_linear640_bf16", 2 * FC, X, M, ldx, W, Wx, N, ln_stats, alpha, nullptr, 0, out, ldo, stats_out, eps, nullptr, 0, 0, stream);
 }

@@ -200,16 +200,22 @@ class _Transformer:
         # C = 320: proj_in, the fused Q / K / V projection, attn1.to_out, attn2.to_q and attn2.to_out run on the panel kernel
         # (sdv_linear320_bf16): bias / LayerNorm fold in the fold k-step (wx), the row statistics leave as (mean, rstd) directly
         self.lin320 = hip.LINEAR320 and self.C == 320
-        if self.lin320:
+        # C = 640 (the 32 x 32 level): the residual-free three of them - proj_in, the fused Q / K / V projection, attn2.to_q - on the
+        # same kernel's 10-slab form (sdv_linear640_bf16); the two to_out projections keep their residual on the igemm
+        self.lin640 = hip.LINEAR320 and hip.LINEAR640 and self.C == 640
+        self.linp = self.lin320 or self.lin640
+        if self.linp:
             z = torch.zeros(self.C, dtype=torch.float32, device=device)
+            nb320 = self.C // 320                        # alpha: one factor per block of 320 output columns
             self.wx_in = ffn_fold_columns(z, self.b_in)
-            self.wx_o1 = ffn_fold_columns(z, self.bo1)
-            self.wx_o2 = ffn_fold_columns(z, self.bo2)
             # (the fold columns carry t / alpha: the kernel multiplies the whole bracket by alpha * rstd)
             self.wx_qkv = ffn_fold_columns(self.sqkv1, torch.cat([tq / qs, tk, tv]))
-            self.al_qkv = torch.tensor([qs, 1.0, 1.0], dtype=torch.float32, device=device)
+            self.al_qkv = torch.tensor([qs] * nb320 + [1.0] * (2 * nb320), dtype=torch.float32, device=device)
             self.wx_q2 = ffn_fold_columns(self.sq2, self.tq2 / qs)
-            self.al_q2 = torch.tensor([qs], dtype=torch.float32, device=device)
+            self.al_q2 = torch.tensor([qs] * nb320, dtype=torch.float32, device=device)
+        if self.lin320:
+            self.wx_o1 = ffn_fold_columns(z, self.bo1)
+            self.wx_o2 = ffn_fold_columns(z, self.bo2)
         if self.ffn_fused:
             self.w1x = ffn_fold_columns(self.sff1, self.bff1)
             self.w2p = ffn_w2_permute(self.wff2)
@@ -269,7 +275,7 @@ class _Transformer:
         if not self.fold:
             return self._call_unfolded(x, nimg, H, W, shared_prefix, out, ctx_of)
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
-        if self.lin320:
+        if self.linp:
             h, st1 = hip.linear320(h, self.w_in, self.wx_in, want_stats=True)
         else:
             h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)        # + (mean, rstd) of every token for norm1
@@ -286,7 +292,7 @@ class _Transformer:
             hip.attention(qk, qk, vt, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=HW, ldo=C, scale=scale, k_off=C,
                           q_prescaled=True)
         else:
-            if self.lin320:
+            if self.linp:
                 qkv = hip.linear320(h, self.wqkv1, self.wx_qkv, ln_stats=st1, alpha=self.al_qkv)      # [Mb, 3C] = [Q * qs | K | V]
             else:
                 qkv = hip.linear(h, self.wqkv1, self.tqkv1, alpha=qs, alpha_cols=C, ln=(st1, self.sqkv1))
@@ -299,7 +305,7 @@ class _Transformer:
         _tap(self.name, "tf_attn1", x=h_in, out=h, nimg=nb, H=H, W=W)
         h_in = h
         # --- cross attention on the text context (LN2 inside the Q projection) ---
-        if self.lin320:
+        if self.linp:
             q = hip.linear320(h, self.wq2, self.wx_q2, ln_stats=st2, alpha=self.al_q2)
         else:
             q = hip.linear(h, self.wq2, self.tq2, alpha=qs, ln=(st2, self.sq2))

@@ -42,7 +42,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 11    # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
+ABI_VERSION = 12    # sdv_abi_version() of the library this binding (struct layouts, signatures) was written against
 
 
 _SIGNATURES = {
@@ -57,6 +57,8 @@ _SIGNATURES = {
     "sdv_ffn_geglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_void_p]),
     "sdv_linear320_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdv_linear640_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_float, C.c_void_p]),
     "sdv_attention_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 9 + [C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "sdv_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -547,13 +549,30 @@ def _linear320_impl(x, w, wx, ln_stats, alpha, residual, out, stats_out, eps, vt
 
 _k_linear320 = _defop("k_linear320(Tensor x, Tensor w, Tensor wx, Tensor? ln_stats, Tensor? alpha, Tensor? residual, Tensor(a!) out, Tensor(b!)? stats_out, "
                       "float eps, Tensor(c!)? vt, int hw) -> ()", _linear320_impl)
+def _linear640_impl(x, w, wx, ln_stats, alpha, out, stats_out, eps):
+    lib = load()
+    M, N = x.shape[0], w.shape[0]
+    if x.shape[1] != 640 or w.shape[1] != 640 or tuple(wx.shape) != (N, 16) or not (w.is_contiguous() and wx.is_contiguous()):
+        raise SdvHipError(f"linear640: x [M, 640], w [N, 640], wx [N, 16] contiguous expected, got {tuple(x.shape)} / {tuple(w.shape)} / {tuple(wx.shape)}")
+    if alpha is not None and alpha.numel() != N // 320:
+        raise SdvHipError("linear640: alpha holds one factor per block of 320 output columns")
+    args = (_ptr(x, BF16, "X"), M, x.stride(0), _ptr(w, BF16, "W"), _ptr(wx, BF16, "Wx"), N, _ptr(ln_stats, F32, "ln_stats"), _ptr(alpha, F32, "alpha"),
+            _ptr(out, BF16, "out"), out.stride(0), _ptr(stats_out, F32, "stats_out"), float(eps))
+    _launch("linear320", dict(M=M, N=N, K=640, flops=2.0 * M * N * 640, bytes=2.0 * M * (640 + N)),
+            lambda: _check(lib.sdv_linear640_bf16(*args, _stream()), "sdv_linear640_bf16"))
+
+
+_k_linear640 = _defop("k_linear640(Tensor x, Tensor w, Tensor wx, Tensor? ln_stats, Tensor? alpha, Tensor(a!) out, Tensor(b!)? stats_out, float eps) -> ()",
+                      _linear640_impl)
+LINEAR640 = os.environ.get("SDV_LINEAR640", "1") != "0"     # A/B knob: 0 = the residual-free C = 640 projections stay on the igemm tiles
 LINEAR320 = os.environ.get("SDV_LINEAR320", "1") != "0"     # A/B knob: 0 = the C = 320 projections on the igemm tiles (round 5)
 QKV_VT = os.environ.get("SDV_QKV_VT", "1") != "0"           # A/B knob: 0 = V stays row-major in the fused [Q | K | V] buffer
 
 
 def linear320(x: torch.Tensor, w: torch.Tensor, wx: torch.Tensor, *, ln_stats=None, alpha=None, residual=None, out=None, want_stats: bool = False,
               eps: float = 1e-5, stats_out=None, vt=None, hw: int = 0):
-    """A C = 320 projection on the panel kernel (``torch.ops.sdv.k_linear320`` -> sdv_linear320_bf16): N = 320 or 960 output
+    """A C = 320 (or, residual-free, C = 640: ``k_linear640`` -> sdv_linear640_bf16, N = 640 / 1920) projection on the panel kernel
+    (``torch.ops.sdv.k_linear320`` -> sdv_linear320_bf16): N = 320 or 960 output
     columns, bias / LayerNorm fold in ``wx`` (``weights.ffn_fold_columns(s, t)``), optional per-320-column ``alpha``, residual and the
     LayerNorm statistics of the stored rows (returned as ``(y, stats [M, 2])`` with ``want_stats``).  ``vt`` [M / hw, 320, ldv]
     (N = 960): the V third is stored transposed per sample of ``hw`` tokens and ``out`` [M, 640] holds only [Q | K]."""
@@ -561,7 +580,12 @@ def linear320(x: torch.Tensor, w: torch.Tensor, wx: torch.Tensor, *, ln_stats=No
     if out is None:
         out = torch.empty((M, w.shape[0] if vt is None else 640), dtype=BF16, device=x.device)
     st = (stats_out if stats_out is not None else torch.empty((M, 2), dtype=F32, device=x.device)) if want_stats else None
-    _k_linear320(x, w, wx, ln_stats, alpha, residual, out, st, float(eps), vt, int(hw))
+    if w.shape[1] == 640:      # the C = 640 form (sdv_linear640_bf16): N = 640 or 1920, no residual, no transposed V
+        if residual is not None or vt is not None:
+            raise SdvHipError("linear320: the K = 640 form takes neither a residual nor a transposed V output")
+        _k_linear640(x, w, wx, ln_stats, alpha, out, st, float(eps))
+    else:
+        _k_linear320(x, w, wx, ln_stats, alpha, residual, out, st, float(eps), vt, int(hw))
     return (out, st) if want_stats else out
 
 

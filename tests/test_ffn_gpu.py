@@ -25,12 +25,12 @@ def _weights(dev, seed=0):
     return dict(w1p=w1p, s1=s1, t1=t1, w1x=ffn_fold_columns(s1, t1), w2=w2.to(dev), w2p=ffn_w2_permute(w2).to(dev), b2=b2.to(dev, F32))
 
 
-def _rows(M, dev, seed, common_mode=3.0):
+def _rows(M, dev, seed, common_mode=3.0, K=C):
     """rows like the UNet's residual stream: a common mode of several sigma, sigma between 0.03 and 2"""
     g = torch.Generator(device=dev).manual_seed(seed)
     mu = torch.randn(M, 1, device=dev, generator=g) * common_mode
     sd = torch.exp(torch.empty(M, 1, device=dev).uniform_(-3.4, 0.7, generator=g))
-    x = (mu + sd * torch.randn((M, C), device=dev, generator=g)).to(BF16)
+    x = (mu + sd * torch.randn((M, K), device=dev, generator=g)).to(BF16)
     xf = x.float()
     st = torch.stack([xf.mean(1), torch.rsqrt(xf.var(1, unbiased=False) + 1e-5)], 1).contiguous()   # what the producer's epilogue emits
     return x, st
@@ -122,36 +122,39 @@ def test_ffn_geglu_common_mode_does_not_leak(hip, dev):
 # ------------------------------------------------------------------------------------------------
 # the C = 320 projections on the panel kernel (sdv_linear320_bf16)
 # ------------------------------------------------------------------------------------------------
-def _lin_forms(hip, dev):
+def _lin_forms(hip, dev, K=C):
+    """the projections of a transformer block with K channels (K = 320: sdv_linear320_bf16, K = 640: sdv_linear640_bf16)"""
     from stable_diffusion_videos_amd.weights import ffn_fold_columns, ln_fold
-    g = torch.Generator().manual_seed(21)
+    g = torch.Generator().manual_seed(21 + K // 640)
     qs = hip.q_prescale(40)
-    gamma, beta = 1.0 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
-    w = lambda: torch.randn(C, C, generator=g) * C ** -0.5
-    bias = (torch.randn(C, generator=g) * 0.2).to(dev)
-    forms = {"bias": dict(w=w().to(dev, BF16), s=torch.zeros(C, device=dev), t=bias, alpha=None)}
+    nb = K // C
+    gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    w = lambda: torch.randn(K, K, generator=g) * K ** -0.5
+    bias = (torch.randn(K, generator=g) * 0.2).to(dev)
+    forms = {"bias": dict(w=w().to(dev, BF16), s=torch.zeros(K, device=dev), t=bias, alpha=None)}
     parts = [ln_fold(w(), gamma, beta, None, dev) for _ in range(3)]
     W3, s3, t3 = (torch.cat([p_[j] for p_ in parts]).contiguous() for j in range(3))
-    forms["qkv"] = dict(w=W3, s=s3, t=t3, alpha=torch.tensor([qs, 1.0, 1.0], device=dev))
+    forms["qkv"] = dict(w=W3, s=s3, t=t3, alpha=torch.tensor([qs] * nb + [1.0] * (2 * nb), device=dev))
     wq, sq, tq = ln_fold(w(), gamma, beta, None, dev)
-    forms["q2"] = dict(w=wq, s=sq, t=tq, alpha=torch.tensor([qs], device=dev))
+    forms["q2"] = dict(w=wq, s=sq, t=tq, alpha=torch.tensor([qs] * nb, device=dev))
     for f in forms.values():
         f["wx"] = ffn_fold_columns(f["s"], f["t"])
     return forms
 
 
-@pytest.mark.parametrize("form,use_res", [("bias", False), ("bias", True), ("qkv", False), ("q2", False)])
+@pytest.mark.parametrize("form,use_res,K", [("bias", False, 320), ("bias", True, 320), ("qkv", False, 320), ("q2", False, 320),
+                                            ("bias", False, 640), ("qkv", False, 640), ("q2", False, 640)])
 @pytest.mark.parametrize("M", [100, 4096 * 5 + 33, 4096 * 36])
-def test_linear320_is_deterministic_and_elementwise_bounded(hip, dev, form, use_res, M):
+def test_linear320_is_deterministic_and_elementwise_bounded(hip, dev, form, use_res, K, M):
     """proj_in / attn.to_out / attn2.to_q / the fused Q K V projection of the C = 320 transformer blocks (Transformer2DModel inside
     unet(...), stable_diffusion_pipeline.py:418) on the panel kernel: every element against float64 within half a bf16 ulp + 2e-5
     of the magnitudes that went into it (rows with a common mode of several sigma: the fold's - mean s rides in the matrix product
     as three-way bf16 splits and has to cancel to fp32 accuracy), four launches bit for bit equal, and the LayerNorm statistics it
     emits for its consumer against the statistics of the rows it stored."""
-    f = _lin_forms(hip, dev)[form]
-    x, st = _rows(M, dev, 31 + M)
+    f = _lin_forms(hip, dev, K)[form]
+    x, st = _rows(M, dev, 31 + M, K=K)
     fold = form != "bias"
-    r = (torch.randn((M, C), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 2.0).to(BF16) if use_res else None
+    r = (torch.randn((M, K), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 2.0).to(BF16) if use_res else None
     run = lambda: hip.linear320(x, f["w"], f["wx"], ln_stats=st if fold else None, alpha=f["alpha"], residual=r, want_stats=not fold)
     outs = [run() for _ in range(4)]
     torch.cuda.synchronize()
@@ -164,8 +167,8 @@ def test_linear320_is_deterministic_and_elementwise_bounded(hip, dev, form, use_
     if f["alpha"] is not None:
         al = f["alpha"].double().repeat_interleave(C)
     worst = 0.0
-    for lo in range(0, M, 32768):
-        sl = slice(lo, min(M, lo + 32768))
+    for lo in range(0, M, 16384):
+        sl = slice(lo, min(M, lo + 16384))
         x64, w64 = x[sl].double(), f["w"].double()
         m64 = st[sl, :1].double() if fold else torch.zeros((x64.shape[0], 1), dtype=torch.float64, device=dev)
         r64 = st[sl, 1:].double() if fold else torch.ones((x64.shape[0], 1), dtype=torch.float64, device=dev)
@@ -175,7 +178,7 @@ def test_linear320_is_deterministic_and_elementwise_bounded(hip, dev, form, use_
             ref, mag = ref + r[sl].double(), mag + r[sl].double().abs()
         ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
         worst = max(worst, float(((y0[sl].double() - ref).abs() / (0.5 * ulp * (1 + 1e-3) + 2e-5 * mag)).max()))
-    msg = f"linear320 {form}{' + residual' if use_res else ''}, M={M}: 4 launches bit-identical, worst element at {worst:.3f} of (half ulp + 2e-5 magnitudes)"
+    msg = f"linear{K} {form}{' + residual' if use_res else ''}, M={M}: 4 launches bit-identical, worst element at {worst:.3f} of (half ulp + 2e-5 magnitudes)"
     if s0 is not None:
         yf = y0.float()
         mean, rstd = yf.mean(1), torch.rsqrt(yf.var(1, unbiased=False) + 1e-5)
@@ -187,17 +190,18 @@ def test_linear320_is_deterministic_and_elementwise_bounded(hip, dev, form, use_
     assert worst <= 1.0
 
 
-def test_linear320_agrees_with_the_igemm_form(hip, dev):
+@pytest.mark.parametrize("K", [320, 640])
+def test_linear320_agrees_with_the_igemm_form(hip, dev, K):
     """The same projection as sdv_gemm_bf16 launches it (LayerNorm fold, alpha on the Q third): same roundings, fp32 summation order
     aside - and the statistics both forms emit lead a consumer to the same normalisation."""
     M = 4096 * 3 + 5
-    f = _lin_forms(hip, dev)["qkv"]
+    f = _lin_forms(hip, dev, K)["qkv"]
     qs = hip.q_prescale(40)
-    x, st = _rows(M, dev, 77)
+    x, st = _rows(M, dev, 77, K=K)
     a = hip.linear320(x, f["w"], f["wx"], ln_stats=st, alpha=f["alpha"])
-    t_scaled = torch.cat([f["t"][:C] * qs, f["t"][C:]])
-    b = hip.linear(x, f["w"], t_scaled, alpha=qs, alpha_cols=C, ln=(st, f["s"]))
-    fb = _lin_forms(hip, dev)["bias"]
+    t_scaled = torch.cat([f["t"][:K] * qs, f["t"][K:]])
+    b = hip.linear(x, f["w"], t_scaled, alpha=qs, alpha_cols=K, ln=(st, f["s"]))
+    fb = _lin_forms(hip, dev, K)["bias"]
     ya, sa = hip.linear320(x, fb["w"], fb["wx"], want_stats=True)
     yb, sb = hip.linear(x, fb["w"], fb["t"], want_stats=True)
     torch.cuda.synchronize()

@@ -21,7 +21,7 @@ def test_c_abi_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libsdv_hip.so does not export {name}"
     assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip.load().sdv_abi_version() == hip.ABI_VERSION == 11
+    assert hip.load().sdv_abi_version() == hip.ABI_VERSION == 12
 
 
 def test_gemm_args_struct_matches_header(hip):
@@ -84,6 +84,17 @@ def test_linear320_argument_validation_without_gpu(hip):
         a = dict(ok)
         a.update(change)
         assert lib.sdv_linear320_bf16(*a.values()) == -1 and word in lib.sdv_last_error(), (change, lib.sdv_last_error())
+
+
+def test_linear640_argument_validation_without_gpu(hip):
+    """sdv_linear640_bf16: N is 640 or 1920, statistics exist for N = 640 only, rows of 640 columns"""
+    lib = hip.load()
+    ok = dict(X=16, M=4096, ldx=640, W=16, Wx=16, N=640, ln_stats=None, alpha=None, out=16, ldo=640, stats_out=None, eps=1e-5, stream=None)
+    for change, word in ((dict(N=320), b"640 or 1920"), (dict(N=1920, ldo=1920, stats_out=16), b"statistics"), (dict(ldx=320), b"leading"),
+                         (dict(N=1920, ldo=640), b"leading"), (dict(out=None), b"null"), (dict(W=24), b"unaligned"), (dict(M=0), b"bad M")):
+        a = dict(ok)
+        a.update(change)
+        assert lib.sdv_linear640_bf16(*a.values()) == -1 and word in lib.sdv_last_error(), (change, lib.sdv_last_error())
 
 
 def test_split_k_planning_without_gpu(hip):
