@@ -274,8 +274,14 @@ class _Transformer:
         scale = dh ** -0.5
         if not self.fold:
             return self._call_unfolded(x, nimg, H, W, shared_prefix, out, ctx_of)
+        # small calls: a persistent panel kernel with fewer panels than CUs loses to the igemm's small tiles (hip.PANEL_MIN_ROWS_*); the
+        # choice is made on the rows of the WHOLE call so that the CFG-shared prefix takes the kernels the unshared forward takes
+        forced = bool(hip.FORCE_TILE)
+        ffn_fused = self.ffn_fused and (forced or M >= hip.PANEL_MIN_ROWS_FFN)
+        lin_in = self.lin320 or (self.lin640 and (forced or M >= hip.PANEL_MIN_ROWS_LIN640))          # proj_in, attn2.to_q
+        lin_qkv = self.lin320 or (self.lin640 and (forced or M >= hip.PANEL_MIN_ROWS_QKV640))
         h = hip.groupnorm(x, self.gn_g, self.gn_b, nimg=nb, HW=HW, groups=self.groups, eps=1e-6, silu=False)
-        if self.linp:
+        if lin_in:
             h, st1 = hip.linear320(h, self.w_in, self.wx_in, want_stats=True)
         else:
             h, st1 = hip.linear(h, self.w_in, self.b_in, want_stats=True)        # + (mean, rstd) of every token for norm1
@@ -292,7 +298,7 @@ class _Transformer:
             hip.attention(qk, qk, vt, o, B=nb, H=heads, Lq=HW, Lk=HW, dh=dh, ldq=2 * C, ldk=2 * C, ldv=HW, ldo=C, scale=scale, k_off=C,
                           q_prescaled=True)
         else:
-            if self.linp:
+            if lin_qkv:
                 qkv = hip.linear320(h, self.wqkv1, self.wx_qkv, ln_stats=st1, alpha=self.al_qkv)      # [Mb, 3C] = [Q * qs | K | V]
             else:
                 qkv = hip.linear(h, self.wqkv1, self.tqkv1, alpha=qs, alpha_cols=C, ln=(st1, self.sqkv1))
@@ -305,7 +311,7 @@ class _Transformer:
         _tap(self.name, "tf_attn1", x=h_in, out=h, nimg=nb, H=H, W=W)
         h_in = h
         # --- cross attention on the text context (LN2 inside the Q projection) ---
-        if self.linp:
+        if lin_in:
             q = hip.linear320(h, self.wq2, self.wx_q2, ln_stats=st2, alpha=self.al_q2)
         else:
             q = hip.linear(h, self.wq2, self.tq2, alpha=qs, ln=(st2, self.sq2))
@@ -338,7 +344,7 @@ class _Transformer:
         _aux(self.name, "st3", st3)
         h_in = h
         # --- GEGLU feed-forward (LN3 inside ff.net.0) ---
-        if self.ffn_fused:
+        if ffn_fused:
             h = hip.ffn_geglu(h, st3, self.wff1, self.w1x, self.w2p, self.bff2)
         else:
             g = hip.linear(h, self.wff1, self.bff1, epi=1, ln=(st3, self.sff1))   # [M, 4C]

@@ -565,6 +565,13 @@ def _linear640_impl(x, w, wx, ln_stats, alpha, out, stats_out, eps):
 _k_linear640 = _defop("k_linear640(Tensor x, Tensor w, Tensor wx, Tensor? ln_stats, Tensor? alpha, Tensor(a!) out, Tensor(b!)? stats_out, float eps) -> ()",
                       _linear640_impl)
 LINEAR640 = os.environ.get("SDV_LINEAR640", "1") != "0"     # A/B knob: 0 = the residual-free C = 640 projections stay on the igemm tiles
+# Rows (of the WHOLE call: samples x pixels of the level, so that the CFG-shared prefix and the unshared forward choose alike) below which
+# a persistent panel kernel leaves most CUs idle and the igemm's small tiles win (tools/r6_small.sh, profiles/round6_small_batches.txt):
+# the fused feed-forward, the C = 640 fused Q K V projection, the other C = 640 projections.  hip.FORCE_TILE - "run what the big batch
+# runs" (bench.py's parity check, the forced-tile tests) - overrides them: a forced forward takes the panel kernels at any size.
+PANEL_MIN_ROWS_FFN = int(os.environ.get("SDV_PANEL_MIN_ROWS_FFN", "16384"))
+PANEL_MIN_ROWS_QKV640 = int(os.environ.get("SDV_PANEL_MIN_ROWS_QKV640", "32768"))
+PANEL_MIN_ROWS_LIN640 = int(os.environ.get("SDV_PANEL_MIN_ROWS_LIN640", "8192"))
 LINEAR320 = os.environ.get("SDV_LINEAR320", "1") != "0"     # A/B knob: 0 = the C = 320 projections on the igemm tiles (round 5)
 QKV_VT = os.environ.get("SDV_QKV_VT", "1") != "0"           # A/B knob: 0 = V stays row-major in the fused [Q | K | V] buffer
 
