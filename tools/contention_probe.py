@@ -34,7 +34,70 @@ def setup(arch):
     return pipe, x2, B, h, step
 
 
+def kernel_noise(seconds, kind):
+    """ONE kind of kernel in a loop (which resource of the CU does the co-resident process have to use for the fault to show?):
+    attn = flash attention (v_exp-heavy, little LDS-DMA), conv = the implicit-GEMM conv (LDS-DMA + MFMA, no transcendental),
+    gn = GroupNorm apply (HBM streaming, no LDS), geglu = the 8-wave GEGLU GEMM (MFMA + transcendentals in the epilogue)"""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *sh: (torch.randn(sh, device=dev, generator=g) * 0.5).to(BF16)
+    if kind == "attn":
+        B, H, L, dh = 8, 8, 4096, 40
+        q, k, v, o = rnd(B * L, H * dh), rnd(B * L, H * dh), rnd(B * L, H * dh), rnd(B * L, H * dh)
+        fn = lambda: hip.attention(q, k, v, o, B=B, H=H, Lq=L, Lk=L, dh=dh, ldq=H * dh, ldk=H * dh, ldv=H * dh, ldo=H * dh, scale=dh ** -0.5, v_rowmajor=True)
+    elif kind == "conv":
+        nimg, Hh, C = 8, 64, 320
+        x, w, b = rnd(nimg * Hh * Hh, C), rnd(C, 9 * C), torch.zeros(C, device=dev)
+        out = torch.empty_like(x)
+        fn = lambda: hip.conv3x3(x, w, b, nimg=nimg, H=Hh, W=Hh, out=out)
+    elif kind == "gn":
+        nimg, HW, C = 8, 4096, 320
+        x, gm, bt = rnd(nimg * HW, C), torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        fn = lambda: hip.groupnorm(x, gm, bt, nimg=nimg, HW=HW, groups=32, eps=1e-5, silu=True)
+    elif kind in ("tile1", "tile2", "tile3"):           # the 4-wave small tiles on a low-resolution shape (plain epilogue)
+        M, C = 2048, 1280
+        x, w, b = rnd(M, C), rnd(C, C), torch.zeros(C, device=dev)
+        fn = lambda: hip.linear(x, w, b, tile=int(kind[-1]))
+    elif kind == "splitk":                               # 8 x 8-level conv, split-K first pass + reduce
+        nimg, Hh, C = 8, 8, 1280
+        x, w, b = rnd(nimg * Hh * Hh, C), rnd(C, 9 * C), torch.zeros(C, device=dev)
+        fn = lambda: hip.conv3x3(x, w, b, nimg=nimg, H=Hh, W=Hh)
+    elif kind == "xattn":                                # text cross-attention (resident K / V form)
+        B, H, L, dh = 8, 8, 4096, 40
+        q, k, vt, o = rnd(B * L, H * dh), rnd(B * 77, H * dh), rnd(B, H * dh, 128), rnd(B * L, H * dh)
+        fn = lambda: hip.attention(q, k, vt, o, B=B, H=H, Lq=L, Lk=77, dh=dh, ldq=H * dh, ldk=H * dh, ldv=128, ldo=H * dh, scale=dh ** -0.5)
+    elif kind == "ffn":                                  # the fused feed-forward panel kernel (one 512-register wave per SIMD, 160 KB of LDS)
+        from stable_diffusion_videos_amd.weights import ffn_fold_columns, ffn_w2_permute
+        M, C = 32768, 320
+        x, w1, w2 = rnd(M, C), rnd(8 * C, C), rnd(C, 4 * C)
+        xf = x.float()
+        st = torch.stack([xf.mean(1), torch.rsqrt(xf.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+        w1x, w2p, b2 = ffn_fold_columns(torch.zeros(8 * C, device=dev), torch.zeros(8 * C, device=dev)), ffn_w2_permute(w2), torch.zeros(C, device=dev)
+        fn = lambda: hip.ffn_geglu(x, st, w1, w1x, w2p, b2)
+    elif kind == "t1geglu":                              # the victim's own kind: fold + GEGLU on a small shape (the library decides the tile)
+        M, C = 2048, 640
+        x, w, b = rnd(M, C), rnd(8 * C, C), torch.zeros(8 * C, device=dev)
+        xf = x.float()
+        st = torch.stack([xf.mean(1), torch.rsqrt(xf.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+        sv = torch.zeros(8 * C, device=dev)
+        fn = lambda: hip.linear(x, w, b, epi=1, ln=(st, sv))
+    else:
+        M, C = 32768, 640
+        x, w, b = rnd(M, C), rnd(8 * C, C), torch.zeros(8 * C, device=dev)
+        fn = lambda: hip.linear(x, w, b, epi=1, tile=6)
+    fn()
+    torch.cuda.synchronize()
+    print("ready", flush=True)
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+
+
 def noise(seconds, arch):
+    if arch in ("attn", "conv", "gn", "geglu", "tile1", "tile2", "tile3", "splitk", "xattn", "t1geglu", "ffn"):
+        return kernel_noise(seconds, arch)
     pipe, x2, B, h, step = setup(arch)
     pipe.unet.forward(x2, 2 * B, h, h, step, cfg_shared=True)
     torch.cuda.synchronize()
@@ -72,6 +135,7 @@ def main():
     while "ready" not in child.stdout.readline():
         pass
     counts = [0] * len(base)
+    dumped = 0
     firsts = {}
     try:
         for r in range(runs):
@@ -82,6 +146,14 @@ def main():
                     counts[i] += 1
                     if first is None:
                         first = n0
+                        if dumped < 6:          # where and by how much: the pattern says which instruction
+                            dumped += 1
+                            a2, b2 = a.reshape(-1, a.shape[-1]).float(), b.reshape(-1, b.shape[-1]).float()
+                            bad = (a2 != b2).nonzero()
+                            rows, cols = bad[:, 0].tolist(), bad[:, 1].tolist()
+                            print(f"  run {r}: {n0} shape {tuple(a2.shape)}: {len(rows)} elements differ; rows {sorted(set(rows))[:40]} cols {sorted(set(cols))[:40]}")
+                            for (rr, cc) in list(zip(rows, cols))[:12]:
+                                print(f"      [{rr}, {cc}] alone {float(a2[rr, cc]):+.5f}  now {float(b2[rr, cc]):+.5f}")
             if first is not None:
                 firsts[first] = firsts.get(first, 0) + 1
     finally:
