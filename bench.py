@@ -349,11 +349,12 @@ def kernel_pass(pipe, embeds, noise, size, steps):
 
 
 def csrc_fingerprint() -> str:
-    """sha256 over the kernel sources + the C header, in name order: what a committed profile was collected FROM.  (The GPU box has
+    """sha256 over the kernel sources + the C header + the build recipe, in name order: what a committed profile was collected FROM.  (The GPU box has
     no .git; the content hash needs none.)"""
     import hashlib
     h = hashlib.sha256()
-    files = sorted((ROOT / "stable_diffusion_videos_amd" / "csrc").glob("*.h*")) + [ROOT / "include" / "sdv_hip.h"]
+    files = (sorted((ROOT / "stable_diffusion_videos_amd" / "csrc").glob("*.h*")) + [ROOT / "include" / "sdv_hip.h"] +
+             [ROOT / "stable_diffusion_videos_amd" / "build.py"])          # (the compiler flags are part of what was measured)
     for f in files:
         h.update(f.name.encode() + b"\0" + f.read_bytes())
     return h.hexdigest()[:16]

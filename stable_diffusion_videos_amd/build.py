@@ -29,7 +29,10 @@ FAST_FLAGS = ["-ffast-math", "-fno-finite-math-only"]
 # attention: MFMA results are consumed by the softmax VALU code straight away - keep them in VGPRs (no
 # v_accvgpr_read/write traffic; 123+32 -> 128 registers, 3 -> 4 waves/SIMD for the 40/64-wide heads)
 EXTRA_FLAGS = {"sdv_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "sdv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # igemm: + no SLP vectoriser - the one result that ever differed under a second process on the GPU came out of a
+               # v_pk_* + transcendental sequence of a GEGLU epilogue and went away without the packed arithmetic (DESIGN.md "The
+               # co-residency finding"); the forward is 0.1 - 0.4 % FASTER without it (same box: 12.33 / 12.36 vs 12.39 / 12.37 frames/s)
+               "sdv_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
                # fused feed-forward: one wave per SIMD with all 512 registers (AGPR-form MFMAs: no vgpr-form here); its VALU stream is
                # laid out by hand beside the MFMAs, where packed fp32 ops (v_pk_fma_f32 out of the SLP vectoriser) are an anti-lever
                "sdv_ffn.hip": ["-fno-slp-vectorize"]}
@@ -47,7 +50,7 @@ def sources():
 
 
 def _newest_dep() -> float:
-    deps = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    deps = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h")) + [Path(__file__)]        # (a changed flag is a changed object)
     return max(p.stat().st_mtime for p in deps)
 
 

@@ -572,7 +572,9 @@ def test_hot_kernels_do_not_spill():
         #  * the GroupNorm-statistics variant (FEAT 4) of the 256 x 320 conv: the statistics butterfly's 16 + 16 values on top of the
         #    conv's addressing state (the statistics live in a variant of their own so that the plain kernels do not pay for them).
         # (round 4 had a fourth exception - the LayerNorm-fold variant of the ring tile 12 - which left with that tile in round 5)
-        exact = {r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb0ELi2ELi9E": 160, r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi9E": 176,
+        # (round 6: sdv_gemm.hip is built without the SLP vectoriser - DESIGN.md "The co-residency finding" -; the DENSE block-scaled
+        #  variant, which no engine launches, went 160 -> 228 B with it, the two conv variants stayed inside their numbers)
+        exact = {r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb0ELi2ELi9E": 228, r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi9E": 176,
                  r"igemm_kernelILi4ELi2ELi2ELi5ELi64ELb1ELi2ELi4E": 140}
 
         def allowed(n):
